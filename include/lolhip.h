@@ -1,0 +1,170 @@
+/*
+ * include/lolhip.h — C ABI of liblolhip.so, the MI355X-native backend for the
+ * Z_q hot path of Lol's `Tensor` class.
+ *
+ * Two groups of entry points:
+ *
+ *  (A) DROP-IN SYMBOLS: the ten `extern "C"` functions lol-cpp exports for Z_q and
+ *      that lol-cpp's Haskell shim binds with `foreign import ccall unsafe`
+ *      (lol-cpp/Crypto/Lol/Cyclotomic/Tensor/CPP/Backend.hs:304-337).  Same names,
+ *      same argument order and meaning, host pointers, in place, one polynomial
+ *      per call — so the existing `CT` shim links against liblolhip unchanged.
+ *      `totm` is declared int64_t because that is what Haskell passes
+ *      (Backend.hs:157; the C++ declares int32 hDim_t, types.h:22).
+ *
+ *  (B) BATCHED PLAN API: what a `lol-hip` backend binds (INTEGRATION.md shows the
+ *      Haskell stubs).  A plan is built once per (prime powers, moduli); data
+ *      stays in HBM; every call takes a leading batch dimension B.
+ *
+ * Data layout everywhere (reference: tensor.h:69, mul.cpp:21, Backend.hs:134-149):
+ *   coefficient j of RNS component t of polynomial b is  y[(b*n + j)*T + t],
+ *   int64, n = totient(m), T = tupSize.  Inputs may be in (-q_t, q_t); outputs are
+ *   always canonical in [0, q_t) (zq.cpp:57-68).
+ *
+ * All functions are re-entrant (no global modulus, cf. types.h:59) and never call
+ * exit() (cf. ASSERT, types.h:36-41): errors come back as status codes.
+ * There is NO CPU fallback: without a usable GPU every compute entry point
+ * returns LOLHIP_ERR_NO_DEVICE.
+ */
+#ifndef LOLHIP_H
+#define LOLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOLHIP_API __attribute__((visibility("default")))
+
+/* == PrimeExponent (types.h:27-31) == Haskell CPP = (Int16, Int16) (Backend.hs:78) */
+typedef struct { int16_t prime; int16_t exponent; } lolhip_pp;
+
+enum {
+  LOLHIP_OK = 0,
+  LOLHIP_ERR_INVALID = -1,      /* malformed prime-power list / sizes                      */
+  LOLHIP_ERR_MODULUS = -2,      /* modulus outside [2, 2^62) or required inverse missing  */
+  LOLHIP_ERR_NO_CRT = -3,       /* no CRT basis mod some q_t (q not prime or m !| q-1)    */
+  LOLHIP_ERR_ROOT = -4,         /* caller-supplied root of unity has the wrong order      */
+  LOLHIP_ERR_NO_DEVICE = -5,    /* no HIP device: compute entry points refuse to run      */
+  LOLHIP_ERR_HIP = -6,          /* HIP runtime error                                      */
+  LOLHIP_ERR_NOT_DIVISIBLE = -7 /* divG: oddRad(m) not invertible mod some q_t            */
+};
+
+/* ------------------------------------------------------------------------- */
+/* (A) drop-in symbols                                                         */
+/* ------------------------------------------------------------------------- */
+
+/* replaces crt.cpp:562-566.  ru[k] = pp_k*tupSize residues, ru[k][i*tupSize+t] =
+ * omega_{pp_k,t}^i (CPP.hs:422-432); the roots the caller chose are honoured. */
+LOLHIP_API void tensorCRTRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr,
+                            int16_t sizeOfPE, int64_t **ru, int64_t *qs);
+/* replaces crt.cpp:569-581 (takes inverse roots and mhat^-1 per component) */
+LOLHIP_API void tensorCRTInvRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr,
+                               int16_t sizeOfPE, int64_t **ruinv, int64_t *mhatInv, int64_t *qs);
+/* replaces mul.cpp:27-30: a = zipWith (*) a b */
+LOLHIP_API void mulRq(int16_t tupSize, int64_t *a, int64_t *b, int64_t totm, int64_t *qs);
+/* replace l.cpp:109-115 / 150-156 */
+LOLHIP_API void tensorLRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+LOLHIP_API void tensorLInvRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+/* replace g.cpp:130-134 / 146-150 */
+LOLHIP_API void tensorGPowRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+LOLHIP_API void tensorGDecRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+/* replace g.cpp:186-207 / 239-260: return 1 on success, 0 on failure (CPP.hs:309-323).
+ * Unlike the reference, y is left untouched when 0 is returned. */
+LOLHIP_API int16_t tensorGInvPowRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+LOLHIP_API int16_t tensorGInvDecRq(int16_t tupSize, int64_t *y, int64_t totm, lolhip_pp *peArr, int16_t sizeOfPE, int64_t *qs);
+/* status of the last drop-in call on this thread (the reference's signatures are void) */
+LOLHIP_API int lolhip_last_status(void);
+
+/* ------------------------------------------------------------------------- */
+/* (B) batched plan API                                                        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct lolhip_plan lolhip_plan;
+typedef struct lolhip_ext lolhip_ext;
+
+/* Build the plan for index m = prod pps (ascending primes, as ppsFact does,
+ * FactoredDefs.hs:360-361) and moduli qs[0..T).  Roots follow Lol's rule: omega_m =
+ * g0^((q-1)/m), g0 the smallest generator of Z_q^* (ZqBasic.hs:144-165).  A plan
+ * without a CRT basis is still valid for L/G/mul/twacePowDec/embedPow/embedDec.
+ * `host_only != 0` skips the device upload (table inspection on a machine
+ * without a GPU; compute calls then fail with LOLHIP_ERR_NO_DEVICE). */
+LOLHIP_API int lolhip_plan_create(const lolhip_pp *pps, int npps, const int64_t *qs, int T,
+                                  int host_only, lolhip_plan **out);
+/* Same, with caller-chosen roots: omega_pp[k*T+t] = primitive pp_k-th root mod q_t,
+ * and mhatinv[T] (either may be NULL for the default rule). */
+LOLHIP_API int lolhip_plan_create_roots(const lolhip_pp *pps, int npps, const int64_t *qs, int T,
+                                        const int64_t *omega_pp, const int64_t *mhatinv,
+                                        int host_only, lolhip_plan **out);
+LOLHIP_API void lolhip_plan_destroy(lolhip_plan *p);
+
+LOLHIP_API int64_t lolhip_plan_n(const lolhip_plan *p);      /* totient(m) */
+LOLHIP_API int64_t lolhip_plan_m(const lolhip_plan *p);
+LOLHIP_API int lolhip_plan_T(const lolhip_plan *p);
+LOLHIP_API int lolhip_plan_has_crt(const lolhip_plan *p);
+/* Host tables exactly as lol-cpp's shim would marshal them.  Each copies min(len,
+ * available) int64 values and returns the available count.
+ *   which: 0 ru[k] (CPP.hs:422-432)   1 ruInv[k] (CPP.hs:434-442)   2 mhatInv
+ *          3 gCRT  4 gInvCRT (CPP.hs:444-454; [n*T] AoS)            5 qs      */
+LOLHIP_API int64_t lolhip_plan_table(const lolhip_plan *p, int which, int k, int64_t *out, int64_t len);
+
+/* smallest prime > lower congruent to 1 mod m (head of goodQs, ZqBasic.hs:71-73) */
+LOLHIP_API int64_t lolhip_good_q(int64_t m, int64_t lower);
+
+/* --- device-pointer batch operations (y, a, b, c live in HBM; stream = hipStream_t
+ *     or NULL).  In place unless noted.  Return LOLHIP_OK or an error. ------------- */
+LOLHIP_API int lolhip_crt_batch   (const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_crtinv_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+/* a *= b pointwise (mulRq / zipWithT (*), CPP.hs:257-260) */
+LOLHIP_API int lolhip_mul_batch   (const lolhip_plan *p, void *stream, int64_t *a, const int64_t *b, int64_t B);
+/* c = crtInv(crt(a) * crt(b)): one cyclotomic ring product per batch item, operands and
+ * result in the powerful basis (Cyc (*), Cyc.hs:262-297).  c may alias a or b. */
+LOLHIP_API int lolhip_polymul_batch(const lolhip_plan *p, void *stream, int64_t *c, const int64_t *a,
+                                    const int64_t *b, int64_t B);
+LOLHIP_API int lolhip_l_batch      (const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_linv_batch   (const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_mulgpow_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_mulgdec_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+/* LOLHIP_ERR_NOT_DIVISIBLE (y untouched) iff the reference would return 0 */
+LOLHIP_API int lolhip_divgpow_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_divgdec_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+/* mulGCRT / divGCRT: pointwise by gCRT / gInvCRT (CPP.hs:230-231) */
+LOLHIP_API int lolhip_mulgcrt_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+LOLHIP_API int lolhip_divgcrt_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
+
+/* --- ring extension m | m' (twace/embed, Extension.hs:54-129) ------------------- */
+LOLHIP_API int lolhip_ext_create(const lolhip_plan *p_m, const lolhip_plan *p_mprime, lolhip_ext **out);
+LOLHIP_API void lolhip_ext_destroy(lolhip_ext *x);
+/* out-of-place gathers; `lo` arrays are [B][n][T], `hi` arrays [B][n'][T] */
+LOLHIP_API int lolhip_twace_powdec_batch(const lolhip_ext *x, void *stream, int64_t *lo_out, const int64_t *hi_in, int64_t B);
+LOLHIP_API int lolhip_twace_crt_batch   (const lolhip_ext *x, void *stream, int64_t *lo_out, const int64_t *hi_in, int64_t B);
+LOLHIP_API int lolhip_embed_pow_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
+LOLHIP_API int lolhip_embed_dec_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
+LOLHIP_API int lolhip_embed_crt_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
+/* host index tables: which 0 extIndicesPowDec[n] 1 extIndicesCRT[n'] 2 embedPow[n'] (-1 = zero)
+ * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468) */
+LOLHIP_API int64_t lolhip_ext_table(const lolhip_ext *x, int which, int32_t *out, int64_t len);
+
+/* --- host-pointer convenience (H2D, run, D2H on an internal stream) --------------
+ * op: see LOLHIP_OP_*.  y (and b for MUL/POLYMUL) are host arrays of B polynomials. */
+enum {
+  LOLHIP_OP_CRT = 0, LOLHIP_OP_CRTINV = 1, LOLHIP_OP_MUL = 2, LOLHIP_OP_POLYMUL = 3,
+  LOLHIP_OP_L = 4, LOLHIP_OP_LINV = 5, LOLHIP_OP_MULGPOW = 6, LOLHIP_OP_MULGDEC = 7,
+  LOLHIP_OP_DIVGPOW = 8, LOLHIP_OP_DIVGDEC = 9, LOLHIP_OP_MULGCRT = 10, LOLHIP_OP_DIVGCRT = 11
+};
+LOLHIP_API int lolhip_op_host(const lolhip_plan *p, int op, int64_t *y, const int64_t *b, int64_t B);
+enum {
+  LOLHIP_EXT_TWACE_POWDEC = 0, LOLHIP_EXT_TWACE_CRT = 1, LOLHIP_EXT_EMBED_POW = 2,
+  LOLHIP_EXT_EMBED_DEC = 3, LOLHIP_EXT_EMBED_CRT = 4
+};
+LOLHIP_API int lolhip_ext_host(const lolhip_ext *x, int op, int64_t *out, const int64_t *in, int64_t B);
+
+/* number of HIP devices visible (0 without a GPU); never initialises a context */
+LOLHIP_API int lolhip_device_count(void);
+LOLHIP_API const char *lolhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOLHIP_H */

@@ -1,0 +1,47 @@
+// lol_amd/csrc/kernels.h — launcher interface between the C ABI (capi.cpp) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "plan.h"
+
+namespace lolhip {
+
+static const int32_t EMBED_NEG_FLAG_DEV = 1 << 30;   // == hostmath.h EMBED_NEG_FLAG
+
+struct Pow2Launch {
+  hipStream_t stream;
+  i64* y;            // in-place operand (modes 0,1) or output c (mode 2)
+  const i64* a;      // mode 2 inputs
+  const i64* b;
+  i64 B;
+  int T;
+  int L;
+  const u64 *tw_fwd, *tw_inv, *scale;
+  const ModCtx* mod;
+};
+// mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
+hipError_t launch_pow2(const Pow2Launch& a, int mode);
+
+struct GenericLaunch {
+  hipStream_t stream;
+  i64* y;
+  i64 B;
+  int T;
+  i64 n;
+  const Stage* stages;
+  int nstages;
+  const u64* consts;
+  int cpc;
+  const ModCtx* mod;
+  u64* scratch;
+  size_t scratch_bytes;
+};
+hipError_t launch_generic(const GenericLaunch& a);
+
+hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod);
+hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,
+                         int T, const ModCtx* mod);
+hipError_t launch_twace_crt(hipStream_t s, i64* out, const i64* in, const int32_t* idx, const i64* tweak, i64 B,
+                            i64 n_out, i64 n_in, int T, const ModCtx* mod);
+
+}  // namespace lolhip

@@ -1,0 +1,345 @@
+// lol_amd/csrc/plan.cpp — plan construction: host tables by Lol's rules, the generic
+// stage programs, the power-of-two Shoup tables, and their upload to HBM.
+#include "plan.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+
+#include "lolhip.h"
+
+namespace lolhip {
+
+namespace {
+
+struct PoolBuilder {
+  int T;
+  std::vector<std::vector<u64>> pool;   // [t][...]
+  explicit PoolBuilder(int T_) : T(T_), pool((size_t)T_) {}
+  int size() const { return (int)pool[0].size(); }
+  // append one table per component; tab[t] all of equal length; returns offset
+  int add(const std::vector<std::vector<u64>>& tab) {
+    int off = size();
+    for (int t = 0; t < T; ++t) pool[(size_t)t].insert(pool[(size_t)t].end(), tab[(size_t)t].begin(), tab[(size_t)t].end());
+    return off;
+  }
+};
+
+struct ProgBuilder {
+  std::vector<Stage> st;
+  void dense(int kind, int p, int d, i64 rts, int wp_off) {
+    Stage s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = kind; s.p = p; s.d = d; s.rts = (int32_t)rts; s.wp_off = wp_off;
+    s.tw_off = -1; s.tw_mod = 1; s.tw_div = 1;
+    st.push_back(s);
+  }
+  // a diagonal between two stages is folded into the stage before it
+  void diag(int tw_off, i64 tw_div, i64 tw_mod) {
+    if (!st.empty() && st.back().tw_off < 0) {
+      st.back().tw_off = tw_off; st.back().tw_div = (int32_t)tw_div; st.back().tw_mod = (int32_t)tw_mod;
+      return;
+    }
+    Stage s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = ST_DIAG; s.p = 1; s.d = 1; s.rts = 1; s.wp_off = 0;
+    s.tw_off = tw_off; s.tw_div = (int32_t)tw_div; s.tw_mod = (int32_t)tw_mod;
+    st.push_back(s);
+  }
+};
+
+// ru-table accessor for component t of prime power k
+struct RuView {
+  const std::vector<i64>& tab; int T; int t;
+  u64 operator()(i64 i) const { return (u64)tab[(size_t)(i * T + t)]; }
+};
+
+}  // namespace
+
+static bool valid_pps(const std::vector<PP>& pps) {
+  int last = 1;
+  for (auto& pe : pps) {
+    if (pe.p <= last || pe.e < 1 || !is_prime((u64)pe.p)) return false;
+    last = pe.p;
+  }
+  return true;
+}
+
+int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>& qs,
+                    const u64* omega_pp_in, const i64* mhatinv_in) {
+  if (!valid_pps(pps) || qs.empty() || qs.size() > 64) return LOLHIP_ERR_INVALID;
+  for (u64 q : qs) if (q < 2 || q >= (1ull << 62)) return LOLHIP_ERR_MODULUS;
+  P.pps = pps;
+  P.T = (int)qs.size();
+  P.qs = qs;
+  P.m = value_pps(pps);
+  P.n = totient_pps(pps);
+  if (P.n > (1 << 24)) return LOLHIP_ERR_INVALID;
+  const int T = P.T, K = (int)pps.size();
+
+  // ---- roots of unity ------------------------------------------------------
+  P.has_crt = true;
+  P.omega_pp.assign((size_t)K, std::vector<u64>((size_t)T, 0));
+  for (int t = 0; t < T; ++t) {
+    if (omega_pp_in) {
+      for (int k = 0; k < K; ++k) P.omega_pp[(size_t)k][(size_t)t] = omega_pp_in[k * T + t] % qs[(size_t)t];
+    } else {
+      u64 w = principal_root((u64)P.m, qs[(size_t)t]);
+      if (w == 0) { P.has_crt = false; break; }
+      for (int k = 0; k < K; ++k) {
+        i64 pp = ipow(pps[(size_t)k].p, pps[(size_t)k].e);
+        P.omega_pp[(size_t)k][(size_t)t] = powmod(w, (u64)(P.m / pp), qs[(size_t)t]);
+      }
+    }
+  }
+  // a caller-supplied root must really have order pp
+  if (P.has_crt && omega_pp_in) {
+    for (int t = 0; t < T && P.has_crt; ++t)
+      for (int k = 0; k < K; ++k) {
+        u64 q = qs[(size_t)t], w = P.omega_pp[(size_t)k][(size_t)t];
+        i64 pp = ipow(pps[(size_t)k].p, pps[(size_t)k].e);
+        if (powmod(w, (u64)pp, q) != 1 % q || powmod(w, (u64)(pp / pps[(size_t)k].p), q) == 1 % q) return LOLHIP_ERR_ROOT;
+      }
+  }
+
+  P.ru.clear(); P.ruinv.clear(); P.mhatinv.assign((size_t)T, 0);
+  P.gcrt.clear(); P.ginvcrt.clear();
+  if (P.has_crt) {
+    P.ru.resize((size_t)K); P.ruinv.resize((size_t)K);
+    for (int k = 0; k < K; ++k) {
+      i64 pp = ipow(pps[(size_t)k].p, pps[(size_t)k].e);
+      P.ru[(size_t)k].assign((size_t)(pp * T), 0);
+      P.ruinv[(size_t)k].assign((size_t)(pp * T), 0);
+      for (int t = 0; t < T; ++t) {
+        u64 q = qs[(size_t)t], w = P.omega_pp[(size_t)k][(size_t)t], wi = invmod(w, q);
+        u64 x = 1 % q, xi = 1 % q;
+        for (i64 i = 0; i < pp; ++i) {
+          P.ru[(size_t)k][(size_t)(i * T + t)] = (i64)x;
+          P.ruinv[(size_t)k][(size_t)(i * T + t)] = (i64)xi;
+          x = mulmod(x, w, q); xi = mulmod(xi, wi, q);
+        }
+      }
+    }
+    for (int t = 0; t < T; ++t) {
+      u64 q = qs[(size_t)t];
+      u64 mh = mhatinv_in ? ((u64)(mhatinv_in[t] % (i64)q + (i64)q)) % q : invmod((u64)value_hat(P.m) % q, q);
+      if (mh == 0 && q != 1) return LOLHIP_ERR_MODULUS;
+      P.mhatinv[(size_t)t] = (i64)mh;
+    }
+    // g vectors (AoS)
+    P.gcrt.assign((size_t)(P.n * T), 0); P.ginvcrt.assign((size_t)(P.n * T), 0);
+    P.has_ginvcrt = true;
+    for (int t = 0; t < T; ++t) {
+      u64 q = qs[(size_t)t];
+      std::vector<u64> wp((size_t)K);
+      bool ginv_ok = true;
+      for (int k = 0; k < K; ++k) {
+        i64 pp = ipow(pps[(size_t)k].p, pps[(size_t)k].e);
+        wp[(size_t)k] = powmod(P.omega_pp[(size_t)k][(size_t)t], (u64)(pp / pps[(size_t)k].p), q);
+        if (pps[(size_t)k].p != 2 && invmod((u64)pps[(size_t)k].p % q, q) == 0) ginv_ok = false;
+      }
+      std::vector<u64> g = g_crt(pps, wp, q, false);
+      for (i64 i = 0; i < P.n; ++i) P.gcrt[(size_t)(i * T + t)] = (i64)g[(size_t)i];
+      if (ginv_ok) {
+        std::vector<u64> gi = g_crt(pps, wp, q, true);
+        for (i64 i = 0; i < P.n; ++i) P.ginvcrt[(size_t)(i * T + t)] = (i64)gi[(size_t)i];
+      } else {
+        P.has_ginvcrt = false;
+      }
+    }
+  }
+  P.oddrad_inv.assign((size_t)T, 0);
+  for (int t = 0; t < T; ++t) P.oddrad_inv[(size_t)t] = invmod(odd_rad(pps) % qs[(size_t)t], qs[(size_t)t]);
+
+  // ---- generic stage programs + constant pool ---------------------------------
+  PoolBuilder pool(T);
+  {  // slot 0: the constant 1 (keeps offsets non-negative and gives an identity diagonal)
+    std::vector<std::vector<u64>> one((size_t)T, std::vector<u64>(1));
+    for (int t = 0; t < T; ++t) one[(size_t)t][0] = 1 % qs[(size_t)t];
+    pool.add(one);
+  }
+  auto per_comp = [&](auto fn, size_t len) {
+    std::vector<std::vector<u64>> tab((size_t)T, std::vector<u64>(len));
+    for (int t = 0; t < T; ++t) fn(t, tab[(size_t)t]);
+    return pool.add(tab);
+  };
+
+  ProgBuilder crt, crtinv;
+  if (P.has_crt) {
+    i64 rts = 1;
+    for (int k = 0; k < K; ++k) {
+      const int p = pps[(size_t)k].p, e = pps[(size_t)k].e;
+      const i64 mprime = ipow(p, e - 1), phi = (p - 1) * mprime;
+      for (int inv = 0; inv < 2; ++inv) {
+        const std::vector<i64>& rutab = inv ? P.ruinv[(size_t)k] : P.ru[(size_t)k];
+        ProgBuilder& pb = inv ? crtinv : crt;
+        // omega_p^j, j < p  (ru[j * p^(e-1)], crt.cpp:526 rustride = mprime)
+        const int wp_off = per_comp([&](int t, std::vector<u64>& o) {
+          RuView r{rutab, T, t};
+          for (int j = 0; j < p; ++j) o[(size_t)j] = r(j * mprime);
+        }, (size_t)p);
+        // crtTwiddle diagonal over the phi(pp) digit (crt.cpp:35-81)
+        int ctw_off = -1;
+        if (mprime > 1)
+          ctw_off = per_comp([&](int t, std::vector<u64>& o) {
+            RuView r{rutab, T, t};
+            for (i64 i0 = 0; i0 < mprime; ++i0)
+              for (int i1 = 0; i1 < p - 1; ++i1)
+                o[(size_t)(i0 * (p - 1) + i1)] = r(digit_rev(p, e - 1, i0) * (i1 + 1));
+          }, (size_t)phi);
+        // dftTwiddle diagonals, one per DFT stage of DFT_{p^(e-1)} (crt.cpp:84-126, 459-516)
+        const int e1 = e - 1;
+        const i64 rts1 = rts * (p - 1);
+        auto dft_diag = [&](int ecur, i64 dim, i64 twidRuStride) -> int {
+          if (dim / p <= 1) return -1;
+          return per_comp([&](int t, std::vector<u64>& o) {
+            RuView r{rutab, T, t};
+            for (i64 c = 0; c < dim; ++c) {
+              i64 i0 = c / p, i1 = c % p;
+              o[(size_t)c] = (i0 == 0 || i1 == 0) ? 1 % qs[(size_t)t] : r(digit_rev(p, ecur - 1, i0) * i1 * twidRuStride);
+            }
+          }, (size_t)dim);
+        };
+        if (!inv) {
+          if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off);
+          if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
+          i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
+          int ecur = e1;
+          for (int i = 0; i < e1; ++i) {
+            const i64 rtsDim = rts1 * rtsScale;
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off);
+            int off = dft_diag(ecur, ltsScale * p, twidRuStride);
+            if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
+            ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
+          }
+        } else {
+          i64 ltsScale = 1, rtsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, twidRuStride = e1 > 0 ? p * ipow(p, e1 - 1) : 0;
+          int ecur = 1;
+          for (int i = 0; i < e1; ++i) {
+            const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
+            int off = dft_diag(ecur, ltsScaleP, twidRuStride);
+            if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off);
+            ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
+          }
+          if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
+          if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off);
+        }
+      }
+      rts *= phi;
+    }
+    // mhat^-1 (crt.cpp:573-579)
+    const int mh_off = per_comp([&](int t, std::vector<u64>& o) { o[0] = (u64)P.mhatinv[(size_t)t]; }, 1);
+    crtinv.diag(mh_off, 1, 1);
+  }
+  const int orad_off = per_comp([&](int t, std::vector<u64>& o) { o[0] = P.oddrad_inv[(size_t)t]; }, 1);
+
+  auto prime_prog = [&](int kind, bool scale) {
+    ProgBuilder pb;
+    i64 rts = 1;
+    for (int k = 0; k < K; ++k) {
+      const int p = pps[(size_t)k].p, e = pps[(size_t)k].e;
+      if (p != 2) pb.dense(kind, p, p - 1, rts, 0);
+      rts *= totient_pp(p, e);
+    }
+    if (scale) pb.diag(orad_off, 1, 1);
+    return pb.st;
+  };
+  P.prog_crt.stages = crt.st;
+  P.prog_crtinv.stages = crtinv.st;
+  P.prog_l.stages = prime_prog(ST_L, false);
+  P.prog_linv.stages = prime_prog(ST_LINV, false);
+  P.prog_gpow.stages = prime_prog(ST_GPOW, false);
+  P.prog_gdec.stages = prime_prog(ST_GDEC, false);
+  P.prog_ginvpow.stages = prime_prog(ST_GINVPOW, true);
+  P.prog_ginvdec.stages = prime_prog(ST_GINVDEC, true);
+
+  P.consts_per_comp = pool.size();
+  P.host_consts.clear();
+  for (int t = 0; t < T; ++t) P.host_consts.insert(P.host_consts.end(), pool.pool[(size_t)t].begin(), pool.pool[(size_t)t].end());
+
+  P.is_pow2 = P.has_crt && K == 1 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
+  P.pow2.L = P.is_pow2 ? pps[0].e - 1 : 0;
+  return LOLHIP_OK;
+}
+
+// ---- device upload -------------------------------------------------------------
+
+#define HIPCK(x) do { if ((x) != hipSuccess) return LOLHIP_ERR_HIP; } while (0)
+
+template <typename Tp>
+static int upload(Tp** dptr, const std::vector<Tp>& h) {
+  *dptr = nullptr;
+  if (h.empty()) return LOLHIP_OK;
+  HIPCK(hipMalloc((void**)dptr, h.size() * sizeof(Tp)));
+  HIPCK(hipMemcpy(*dptr, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  return LOLHIP_OK;
+}
+
+static int upload_prog(StageProgram& sp) {
+  sp.nstages = (int)sp.stages.size();
+  return upload(&sp.d_stages, sp.stages);
+}
+
+int plan_upload(Plan& P) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return LOLHIP_ERR_NO_DEVICE;
+  const int T = P.T;
+  std::vector<ModCtx> mods;
+  for (int t = 0; t < T; ++t) mods.push_back(make_modctx(P.qs[(size_t)t]));
+  int rc;
+  if ((rc = upload(&P.d_mod, mods))) return rc;
+  if ((rc = upload(&P.d_consts, P.host_consts))) return rc;
+  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
+  for (auto* sp : progs) if ((rc = upload_prog(*sp))) return rc;
+  if ((rc = upload(&P.d_gcrt, P.gcrt))) return rc;
+  if ((rc = upload(&P.d_ginvcrt, P.ginvcrt))) return rc;
+
+  if (P.is_pow2) {
+    const int L = P.pow2.L;
+    const i64 n = P.n;
+    std::vector<u64> fwd((size_t)(T * n * 2), 0), inv((size_t)(T * n * 2), 0), sc((size_t)(T * 2), 0);
+    for (int t = 0; t < T; ++t) {
+      const u64 q = P.qs[(size_t)t];
+      const u64 S = (u64)P.mhatinv[(size_t)t];
+      ShoupW ss = make_shoup(S, q);
+      sc[(size_t)(t * 2)] = ss.w; sc[(size_t)(t * 2 + 1)] = ss.wp;
+      for (int s = 1; s <= L; ++s) {
+        const i64 N = (i64)1 << s, half = N >> 1, step = n / N;
+        for (i64 i = 0; i < half; ++i) {
+          const i64 ex = step * (2 * i + 1);                  // < 2n = m
+          u64 w = (u64)P.ru[0][(size_t)(ex * T + t)];
+          u64 wi = (u64)P.ruinv[0][(size_t)(ex * T + t)];
+          if (s == 1) wi = mulmod(wi, S, q);                   // level 1 of the inverse carries mhat^-1
+          ShoupW a = make_shoup(w, q), b = make_shoup(wi, q);
+          const size_t o = ((size_t)t * n + (size_t)(half + i)) * 2;
+          fwd[o] = a.w; fwd[o + 1] = a.wp;
+          inv[o] = b.w; inv[o + 1] = b.wp;
+        }
+      }
+    }
+    if ((rc = upload(&P.pow2.d_tw_fwd, fwd))) return rc;
+    if ((rc = upload(&P.pow2.d_tw_inv, inv))) return rc;
+    if ((rc = upload(&P.pow2.d_scale, sc))) return rc;
+  }
+  // polynomials too large for the LDS ping-pong run the generic path out of HBM scratch
+  if (2 * (size_t)P.n * sizeof(u64) > 152 * 1024) {
+    P.scratch_bytes = (size_t)512 * 2 * (size_t)P.n * sizeof(u64);
+    HIPCK(hipMalloc((void**)&P.d_scratch, P.scratch_bytes));
+  }
+  P.device = true;
+  return LOLHIP_OK;
+}
+
+void plan_free_device(Plan& P) {
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_scratch);
+  fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
+  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
+  for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
+  P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr; P.d_scratch = nullptr;
+  P.pow2 = Pow2Tables();
+  P.device = false;
+}
+
+}  // namespace lolhip

@@ -1,0 +1,107 @@
+// lol_amd/csrc/plan.h — the run-time "plan": everything the reference recomputes or
+// re-marshals per call (twiddle vectors CPP.hs:422-442, g vectors CPP.hs:444-454,
+// moduli Backend.hs:195-199, prime-power list CPP.hs:325-337), built once per
+// (prime powers, moduli, roots) and kept resident in HBM.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "hostmath.h"
+#include "zq_dev.h"
+
+namespace lolhip {
+
+// ---- generic (any m) stage program ----------------------------------------
+// One stage = (I_lts (x) A (x) I_rts) on a length-n planar component, written
+// out-of-place:  out[x] = post[x] * sum_c M(row,c) * (pre * in)[base + c*rts]
+// (tensor.h:39-95 gives the lts/rts bookkeeping this flattens).
+enum StageKind : int32_t {
+  ST_DIAG = 0,     // out[x] = tw[x'] * in[x]                    crtTwiddle (crt.cpp:35-81)
+  ST_DFTP = 1,     // p-point DFT, optional post/pre twiddle     dftp+dftTwiddle (crt.cpp:131-246, 84-126)
+  ST_CRTP = 2,     // (p-1)-point CRT_p                          crtp (crt.cpp:248-346)
+  ST_CRTPINV = 3,  // scaled inverse CRT_p                       crtpinv (crt.cpp:349-457)
+  ST_L = 4,        // prefix sums                                lp (l.cpp:28-57)
+  ST_LINV = 5,     // adjacent differences                       lpInv (l.cpp:67-98)
+  ST_GPOW = 6,     //                                            gPow (g.cpp:16-35)
+  ST_GDEC = 7,     //                                            gDec (g.cpp:37-58)
+  ST_GINVPOW = 8,  //                                            gInvPow (g.cpp:60-90)
+  ST_GINVDEC = 9,  //                                            gInvDec (g.cpp:92-123)
+  ST_SCALE = 10    // out[x] = s * in[x]  (mhatInv crt.cpp:573-579, oddRad^-1 g.cpp:194-204)
+};
+
+struct Stage {
+  int32_t kind;
+  int32_t p;        // prime
+  int32_t d;        // vector length (p or p-1; 1 for DIAG/SCALE)
+  int32_t rts;      // stride between vector elements
+  int32_t wp_off;   // offset (u64 units, per component) of omega_p^j table, j < p
+  int32_t tw_off;   // offset of diagonal table or -1
+  int32_t tw_mod;   // diagonal index = (x / tw_div) % tw_mod
+  int32_t tw_div;
+  int32_t tw_pre;   // 1: multiply the INPUT element by tw (inverse transforms); 0: the output
+  int32_t pad[3];
+};
+
+struct StageProgram {
+  std::vector<Stage> stages;   // host copy
+  Stage* d_stages = nullptr;   // device copy
+  int nstages = 0;
+};
+
+// ---- power-of-two fast path -------------------------------------------------
+struct Pow2Tables {
+  int L = 0;                       // n = 2^L
+  // per component t, n Shoup pairs: entry (N/2 + i) = psi_N^(2i+1), N = 2..n (entry 0 unused)
+  u64* d_tw_fwd = nullptr;         // [T][n][2]
+  u64* d_tw_inv = nullptr;         // [T][n][2]  inverse twiddles; the level-1 entry is pre-scaled
+  u64* d_scale = nullptr;          // [T][2]     Shoup pair of mhatInv
+};
+
+struct Plan {
+  std::vector<PP> pps;
+  int T = 0;
+  i64 m = 0, n = 0;
+  std::vector<u64> qs;
+  bool has_crt = false;            // every q_t prime with m | q_t - 1 (or caller-supplied roots)
+  bool device = false;             // device tables uploaded
+
+  // host tables (the reference's marshalled arguments)
+  std::vector<std::vector<u64>> omega_pp;   // [k][t]   omega_{pp_k} mod q_t
+  std::vector<std::vector<i64>> ru, ruinv;  // [k][pp_k*T] interleaved, tensor.h:91
+  std::vector<i64> mhatinv;                 // [T]
+  std::vector<i64> gcrt, ginvcrt;           // [n*T] AoS
+  std::vector<u64> oddrad_inv;              // [T], 0 when not invertible
+  bool has_ginvcrt = false;                 // every odd p | m invertible mod every q_t
+  std::vector<u64> host_consts;             // [T][consts_per_comp] generic-path constant pool
+
+  // device tables
+  ModCtx* d_mod = nullptr;                  // [T]
+  u64* d_consts = nullptr;                  // generic-path constant pool, [T][consts_per_comp]
+  int consts_per_comp = 0;
+  StageProgram prog_crt, prog_crtinv, prog_l, prog_linv, prog_gpow, prog_gdec, prog_ginvpow, prog_ginvdec;
+  i64* d_gcrt = nullptr;                    // [n*T]
+  i64* d_ginvcrt = nullptr;                 // [n*T]
+  Pow2Tables pow2;
+  bool is_pow2 = false;
+  u64* d_scratch = nullptr;                 // ping-pong space for polynomials too large for LDS
+  size_t scratch_bytes = 0;
+};
+
+// ring-extension plan for m | m'
+struct ExtPlan {
+  const Plan* lo = nullptr;    // index m
+  const Plan* hi = nullptr;    // index m'
+  ExtTables host;
+  int32_t *d_twace_powdec = nullptr, *d_ext_crt = nullptr, *d_embed_pow = nullptr,
+          *d_embed_dec = nullptr, *d_embed_crt = nullptr;
+  std::vector<i64> tweak;      // [n'*T] AoS, twaceCRT's tweak vector (Extension.hs:110-125)
+  i64* d_tweak = nullptr;
+};
+
+// plan.cpp
+int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>& qs,
+                    const u64* omega_pp /* [npp*T] or null */, const i64* mhatinv /* [T] or null */);
+int plan_upload(Plan& P);
+void plan_free_device(Plan& P);
+
+}  // namespace lolhip

@@ -1,0 +1,111 @@
+// lol_amd/csrc/zq_dev.h — Z_q arithmetic for gfx950 device code (and a host mirror
+// of the constant derivations).
+//
+// Replaces the reference's `Zq` class (lol-cpp/.../CPP/types.h:52-94), which reduces
+// with a 64-bit `%` after every operation and keeps a process-global modulus.  Here:
+//   * multiplications by plan constants (twiddles, scales) use Shoup's precomputed-
+//     quotient form with Harvey-style lazy ranges ([0,2q) / [0,4q)), integer only;
+//   * variable*variable products (pointwise mul, dense p-point stages) use an exact
+//     128/64 remainder by a precomputed reciprocal (Moeller-Granlund);
+//   * every kernel canonicalises to [0,q) exactly once before its final store,
+//     which is the reference's post-condition (zq.cpp:57-68).
+// Valid for any modulus 2 <= q < 2^62 (even moduli included; the reference's own
+// correct range is q < ~2^31.5, types.h:79-84).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LH_HD __host__ __device__ __forceinline__
+#define LH_D __device__ __forceinline__
+#else
+#define LH_HD inline
+#define LH_D inline
+#endif
+
+namespace lolhip {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int64_t i64;
+
+// Per-modulus context for exact (a*b) mod q with arbitrary operands.
+struct ModCtx {
+  u64 q;   // modulus
+  u64 d;   // q << s, top bit set
+  u64 v;   // floor((2^128-1)/d) - 2^64
+  u32 s;   // normalisation shift (>= 2 because q < 2^62)
+  u32 pad;
+};
+
+// Shoup pair: w and floor(w * 2^64 / q)
+struct ShoupW { u64 w, wp; };
+
+// host-side derivations (used by plan.cpp)
+inline ModCtx make_modctx(u64 q) {
+  ModCtx c;
+  c.q = q;
+  c.s = (u32)__builtin_clzll(q);
+  c.d = q << c.s;
+  c.v = (u64)((~(unsigned __int128)0) / c.d - ((unsigned __int128)1 << 64));
+  c.pad = 0;
+  return c;
+}
+inline ShoupW make_shoup(u64 w, u64 q) {
+  ShoupW s;
+  s.w = w;
+  s.wp = (u64)((((unsigned __int128)w) << 64) / q);
+  return s;
+}
+
+#if defined(__HIPCC__)
+
+LH_D u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// x - m if x >= m else x; requires x, m < 2^63
+LH_D u64 csub(u64 x, u64 m) {
+  u64 t = x - m;
+  return ((i64)t < 0) ? x : t;
+}
+
+// canonical representative of a reference-style input in (-q, q)
+LH_D u64 canon_in(i64 x, u64 q) { return x < 0 ? (u64)(x + (i64)q) : (u64)x; }
+
+// w*y mod q in [0, 2q) for ANY 64-bit y (w < q)
+LH_D u64 shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
+  u64 Q = mulhi64(wp, y);
+  return w * y - Q * q;
+}
+
+// remainder of the 128-bit value (u1:u0) by c.q, requires (u1:u0) < q * 2^64
+LH_D u64 rem128(u64 x1, u64 x0, const ModCtx& c) {
+  // normalise
+  u64 u1 = (x1 << c.s) | (x0 >> (64 - c.s));
+  u64 u0 = x0 << c.s;
+  // Moeller-Granlund 2-by-1 division step
+  unsigned __int128 qq = (unsigned __int128)c.v * u1 + (((unsigned __int128)u1 << 64) | u0);
+  u64 q1 = (u64)(qq >> 64) + 1, q0 = (u64)qq;
+  u64 r = u0 - q1 * c.d;
+  if (r > q0) r += c.d;
+  if (r >= c.d) r -= c.d;
+  return r >> c.s;
+}
+
+// exact a*b mod q, a,b < q
+LH_D u64 mulmod(u64 a, u64 b, const ModCtx& c) {
+  unsigned __int128 z = (unsigned __int128)a * b;
+  return rem128((u64)(z >> 64), (u64)z, c);
+}
+
+// arbitrary 128-bit value mod q
+LH_D u64 reduce128(u64 x1, u64 x0, const ModCtx& c) {
+  u64 r1 = rem128(0, x1, c);
+  return rem128(r1, x0, c);
+}
+
+LH_D u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+LH_D u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+
+#endif  // __HIPCC__
+
+}  // namespace lolhip

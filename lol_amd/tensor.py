@@ -1,0 +1,327 @@
+"""lol_amd/tensor.py — ctypes binding of include/lolhip.h, shaped like Lol's `Tensor` class.
+
+Method names follow the reference's class methods (lol/Crypto/Lol/Cyclotomic/Tensor.hs:86-193):
+crt, crtInv, l, lInv, mulGPow, mulGDec, divGPow, divGDec, mulGCRT, divGCRT,
+twacePowDec, twaceCRT, embedPow, embedDec, embedCRT, plus zipWithT (*) as `mul` and
+the fused ring product `polymul` (Cyc (*), lol/Crypto/Lol/Cyclotomic/Cyc.hs:262-297).
+
+Arrays are int64 with shape [..., n, T] (T = number of RNS moduli; a trailing axis of
+length 1 for a single modulus) — the reference's AoS layout (tensor.h:69).
+`divG*` return None where the reference returns Nothing (CPP.hs:309-323).
+
+Two calling styles per operation:
+  * numpy arrays  -> host round trip through `lolhip_op_host`
+  * torch CUDA int64 tensors (or raw device pointers via *_dev) -> in place in HBM
+Neither has a CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+OK, ERR_INVALID, ERR_MODULUS, ERR_NO_CRT, ERR_ROOT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_DIVISIBLE = 0, -1, -2, -3, -4, -5, -6, -7
+_ERRNAMES = {ERR_INVALID: "invalid argument", ERR_MODULUS: "modulus out of range / missing inverse",
+             ERR_NO_CRT: "no CRT basis for this modulus", ERR_ROOT: "bad root of unity",
+             ERR_NO_DEVICE: "no HIP device (liblolhip has no CPU fallback)", ERR_HIP: "HIP runtime error",
+             ERR_NOT_DIVISIBLE: "not divisible by g"}
+
+OP_CRT, OP_CRTINV, OP_MUL, OP_POLYMUL, OP_L, OP_LINV, OP_MULGPOW, OP_MULGDEC, OP_DIVGPOW, OP_DIVGDEC, OP_MULGCRT, OP_DIVGCRT = range(12)
+EXT_TWACE_POWDEC, EXT_TWACE_CRT, EXT_EMBED_POW, EXT_EMBED_DEC, EXT_EMBED_CRT = range(5)
+
+
+class LolHipError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__(f"lolhip: {_ERRNAMES.get(code, code)} ({code}) {what}")
+
+
+class NoDeviceError(LolHipError):
+    pass
+
+
+class _PP(C.Structure):
+    _fields_ = [("prime", C.c_int16), ("exponent", C.c_int16)]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "liblolhip.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load liblolhip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(path)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    pp = C.POINTER(_PP)
+    L.lolhip_plan_create.argtypes = [pp, ci, _i64p, ci, ci, C.POINTER(vp)]
+    L.lolhip_plan_create_roots.argtypes = [pp, ci, _i64p, ci, _i64p, _i64p, ci, C.POINTER(vp)]
+    L.lolhip_plan_destroy.argtypes = [vp]
+    L.lolhip_plan_destroy.restype = None
+    for nm in ("lolhip_plan_n", "lolhip_plan_m"):
+        getattr(L, nm).argtypes = [vp]
+        getattr(L, nm).restype = i64
+    L.lolhip_plan_T.argtypes = [vp]
+    L.lolhip_plan_has_crt.argtypes = [vp]
+    L.lolhip_plan_table.argtypes = [vp, ci, ci, _i64p, i64]
+    L.lolhip_plan_table.restype = i64
+    L.lolhip_good_q.argtypes = [i64, i64]
+    L.lolhip_good_q.restype = i64
+    for nm in ("crt", "crtinv", "l", "linv", "mulgpow", "mulgdec", "divgpow", "divgdec", "mulgcrt", "divgcrt"):
+        getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, i64]
+    L.lolhip_mul_batch.argtypes = [vp, vp, vp, vp, i64]
+    L.lolhip_polymul_batch.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.lolhip_ext_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.lolhip_ext_destroy.argtypes = [vp]
+    L.lolhip_ext_destroy.restype = None
+    for nm in ("twace_powdec", "twace_crt", "embed_pow", "embed_dec", "embed_crt"):
+        getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, vp, i64]
+    L.lolhip_ext_table.argtypes = [vp, ci, _i32p, i64]
+    L.lolhip_ext_table.restype = i64
+    L.lolhip_op_host.argtypes = [vp, ci, _i64p, _i64p, i64]
+    L.lolhip_ext_host.argtypes = [vp, ci, _i64p, _i64p, i64]
+    L.lolhip_device_count.restype = ci
+    L.lolhip_version.restype = C.c_char_p
+    L.lolhip_last_status.restype = ci
+    _lib = L
+    return L
+
+
+def _check(rc, what=""):
+    if rc == OK:
+        return
+    raise (NoDeviceError if rc == ERR_NO_DEVICE else LolHipError)(rc, what)
+
+
+def device_count() -> int:
+    return lib().lolhip_device_count()
+
+
+def good_q(m: int, lower: int) -> int:
+    """Head of `goodQs m lower` (ZqBasic.hs:71-73)."""
+    return int(lib().lolhip_good_q(m, lower))
+
+
+def factor_pps(m: int):
+    """ppsFact (FactoredDefs.hs:360-361): [(p, e)] ascending."""
+    out, p = [], 2
+    while m > 1:
+        if m % p == 0:
+            e = 0
+            while m % p == 0:
+                m //= p
+                e += 1
+            out.append((p, e))
+        p += 1 if p == 2 else 2
+        if p * p > m and m > 1:
+            out.append((m, 1))
+            break
+    return out
+
+
+def _np(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_i64p)
+
+
+def _devptr(x):
+    """raw device address of a torch CUDA int64 tensor, or an int address"""
+    if isinstance(x, int):
+        return x
+    if not (x.is_cuda and x.is_contiguous() and x.dtype.__str__() == "torch.int64"):
+        raise TypeError("expected a contiguous int64 CUDA tensor")
+    return x.data_ptr()
+
+
+def _stream(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return torch.cuda.current_stream().cuda_stream
+        except ImportError:
+            pass
+        return 0
+    return int(stream)
+
+
+class Plan:
+    """Twiddles, g vectors, stage programs and moduli for one (m, moduli), resident in HBM.
+
+    Mirrors what lol-cpp's shim marshals per call: `ru`/`ruInv` (CPP.hs:422-442),
+    `mhatInv` (ZqBasic.hs:167-171), `gCRT`/`gInvCRT` (CPP.hs:444-454), the prime-power
+    list (CPP.hs:325-337) and the moduli (Backend.hs:195-199)."""
+
+    def __init__(self, pps, qs, host_only=False, omega_pp=None, mhatinv=None):
+        self.pps = [(int(p), int(e)) for p, e in pps]
+        self.qs = [int(q) for q in qs]
+        arr = (_PP * max(1, len(self.pps)))()
+        for i, (p, e) in enumerate(self.pps):
+            arr[i].prime, arr[i].exponent = p, e
+        qa = (C.c_int64 * len(self.qs))(*self.qs)
+        h = C.c_void_p()
+        L = lib()
+        if omega_pp is None and mhatinv is None:
+            rc = L.lolhip_plan_create(arr, len(self.pps), qa, len(self.qs), int(host_only), C.byref(h))
+        else:
+            om = None if omega_pp is None else (C.c_int64 * len(omega_pp))(*[int(v) for v in omega_pp])
+            mh = None if mhatinv is None else (C.c_int64 * len(mhatinv))(*[int(v) for v in mhatinv])
+            rc = L.lolhip_plan_create_roots(arr, len(self.pps), qa, len(self.qs), om, mh, int(host_only), C.byref(h))
+        _check(rc, f"plan_create(pps={self.pps}, qs={self.qs})")
+        self._h = h
+        self.n = int(L.lolhip_plan_n(h))
+        self.m = int(L.lolhip_plan_m(h))
+        self.T = int(L.lolhip_plan_T(h))
+        self.has_crt = bool(L.lolhip_plan_has_crt(h))
+
+    @classmethod
+    def for_index(cls, m, qs, **kw):
+        return cls(factor_pps(m), qs, **kw)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.lolhip_plan_destroy(h)
+
+    # ---- tables -------------------------------------------------------------------
+    def _table(self, which, k=0):
+        L = lib()
+        cnt = L.lolhip_plan_table(self._h, which, k, None, 0)
+        out = np.zeros(cnt, dtype=np.int64)
+        if cnt:
+            L.lolhip_plan_table(self._h, which, k, out.ctypes.data_as(_i64p), cnt)
+        return out
+
+    def ru(self, k): return self._table(0, k)
+    def ruInv(self, k): return self._table(1, k)
+    def mhatInv(self): return self._table(2)
+    def gCRT(self): return self._table(3).reshape(self.n, self.T)
+    def gInvCRT(self): return self._table(4).reshape(self.n, self.T)
+
+    # ---- helpers ------------------------------------------------------------------
+    def _batch(self, a):
+        per = self.n * self.T
+        if a.size % per:
+            raise ValueError(f"array of {a.size} residues is not a whole number of [n={self.n}, T={self.T}] polynomials")
+        return a.size // per
+
+    def _host(self, op, y, b=None):
+        y, yp = _np(y)
+        y = y.copy()
+        yp = y.ctypes.data_as(_i64p)
+        B = self._batch(y)
+        bp = None
+        if b is not None:
+            b, bp = _np(b)
+            if b.size != y.size:
+                raise ValueError("operand shapes differ")
+        rc = lib().lolhip_op_host(self._h, op, yp, bp, B)
+        if rc == ERR_NOT_DIVISIBLE:
+            return None
+        _check(rc)
+        return y
+
+    def _dev(self, name, y, stream):
+        B = self._batch_t(y)
+        rc = getattr(lib(), f"lolhip_{name}_batch")(self._h, _stream(stream), _devptr(y), B)
+        if rc == ERR_NOT_DIVISIBLE:
+            return None
+        _check(rc)
+        return y
+
+    def _batch_t(self, t):
+        per = self.n * self.T
+        numel = t.numel()
+        if numel % per:
+            raise ValueError("tensor is not a whole number of polynomials")
+        return numel // per
+
+    def _op(self, op, name, y, stream=None):
+        if isinstance(y, np.ndarray) or isinstance(y, (list, tuple)):
+            return self._host(op, y)
+        return self._dev(name, y, stream)
+
+    # ---- the Tensor interface (in place for device tensors, copies for numpy) -----
+    def crt(self, y, stream=None): return self._op(OP_CRT, "crt", y, stream)
+    def crtInv(self, y, stream=None): return self._op(OP_CRTINV, "crtinv", y, stream)
+    def l(self, y, stream=None): return self._op(OP_L, "l", y, stream)
+    def lInv(self, y, stream=None): return self._op(OP_LINV, "linv", y, stream)
+    def mulGPow(self, y, stream=None): return self._op(OP_MULGPOW, "mulgpow", y, stream)
+    def mulGDec(self, y, stream=None): return self._op(OP_MULGDEC, "mulgdec", y, stream)
+    def divGPow(self, y, stream=None): return self._op(OP_DIVGPOW, "divgpow", y, stream)
+    def divGDec(self, y, stream=None): return self._op(OP_DIVGDEC, "divgdec", y, stream)
+    def mulGCRT(self, y, stream=None): return self._op(OP_MULGCRT, "mulgcrt", y, stream)
+    def divGCRT(self, y, stream=None): return self._op(OP_DIVGCRT, "divgcrt", y, stream)
+
+    def mul(self, a, b, stream=None):
+        """zipWithT (*): a * b pointwise (a is overwritten when it is a device tensor)."""
+        if isinstance(a, np.ndarray):
+            return self._host(OP_MUL, a, b)
+        _check(lib().lolhip_mul_batch(self._h, _stream(stream), _devptr(a), _devptr(b), self._batch_t(a)))
+        return a
+
+    def polymul(self, a, b, out=None, stream=None):
+        """crtInv(crt a * crt b): one ring product per batch item, powerful basis in and out."""
+        if isinstance(a, np.ndarray):
+            return self._host(OP_POLYMUL, a, b)
+        out = a if out is None else out
+        _check(lib().lolhip_polymul_batch(self._h, _stream(stream), _devptr(out), _devptr(a), _devptr(b), self._batch_t(a)))
+        return out
+
+
+class Ext:
+    """Index tables and kernels for a ring extension m | m' (Tensor.hs:390-509, Extension.hs:54-129)."""
+
+    def __init__(self, lo: Plan, hi: Plan):
+        self.lo, self.hi = lo, hi
+        h = C.c_void_p()
+        _check(lib().lolhip_ext_create(lo._h, hi._h, C.byref(h)), "ext_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.lolhip_ext_destroy(h)
+
+    def table(self, which):
+        L = lib()
+        cnt = L.lolhip_ext_table(self._h, which, None, 0)
+        out = np.zeros(cnt, dtype=np.int32)
+        if cnt:
+            L.lolhip_ext_table(self._h, which, out.ctypes.data_as(_i32p), cnt)
+        return out
+
+    def _run(self, op, name, x, to_hi, out, stream):
+        src, dst = (self.lo, self.hi) if to_hi else (self.hi, self.lo)
+        if isinstance(x, np.ndarray):
+            x, xp = _np(x)
+            B = src._batch(x)
+            res = np.zeros((B, dst.n, dst.T), dtype=np.int64)
+            _check(lib().lolhip_ext_host(self._h, op, res.ctypes.data_as(_i64p), xp, B))
+            return res
+        B = src._batch_t(x)
+        if out is None:
+            import torch
+            out = torch.empty((B, dst.n, dst.T), dtype=torch.int64, device=x.device)
+        _check(getattr(lib(), f"lolhip_{name}_batch")(self._h, _stream(stream), _devptr(out), _devptr(x), B))
+        return out
+
+    def twacePowDec(self, x, out=None, stream=None): return self._run(EXT_TWACE_POWDEC, "twace_powdec", x, False, out, stream)
+    def twaceCRT(self, x, out=None, stream=None): return self._run(EXT_TWACE_CRT, "twace_crt", x, False, out, stream)
+    def embedPow(self, x, out=None, stream=None): return self._run(EXT_EMBED_POW, "embed_pow", x, True, out, stream)
+    def embedDec(self, x, out=None, stream=None): return self._run(EXT_EMBED_DEC, "embed_dec", x, True, out, stream)
+    def embedCRT(self, x, out=None, stream=None): return self._run(EXT_EMBED_CRT, "embed_crt", x, True, out, stream)
