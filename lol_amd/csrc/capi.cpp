@@ -76,6 +76,8 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
   Pow2Launch l;
   l.stream = s; l.y = y; l.a = a; l.b = b; l.B = B; l.T = P.T; l.L = P.pow2.L;
   l.tw_fwd = P.pow2.d_tw_fwd; l.tw_inv = P.pow2.d_tw_inv; l.scale = P.pow2.d_scale; l.mod = P.d_mod;
+  l.approx = true;
+  for (u64 q : P.qs) if (q >= (1ull << 61)) l.approx = false;
   return launch_pow2(l, mode) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
@@ -163,7 +165,8 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   if (B < 0 || (B > 0 && (!a || !b || !c))) return LOLHIP_ERR_INVALID;
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
-  if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
+  // the kernel parks crt(a) in c before it reads b: hand it the operand that aliases c first
+  if (P.is_pow2) return (c == b) ? run_pow2(P, 2, s, c, b, a, B) : run_pow2(P, 2, s, c, a, b, B);
   // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.
   const size_t bytes = sizeof(int64_t) * (size_t)(B * P.n * P.T);
   if (bytes == 0) return LOLHIP_OK;

@@ -18,6 +18,7 @@ struct Pow2Launch {
   int L;
   const u64 *tw_fwd, *tw_inv, *scale;
   const ModCtx* mod;
+  bool approx;       // every modulus < 2^61: 9-multiply approximate-quotient butterflies
 };
 // mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
 hipError_t launch_pow2(const Pow2Launch& a, int mode);

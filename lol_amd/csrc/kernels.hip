@@ -31,122 +31,383 @@ namespace lolhip {
 // psi_N^(2i+1), i = x mod N/2, psi_N = psi^(n/N).  The inverse runs the levels
 // backwards with Gentleman-Sande butterflies and folds mhat^-1 into level 1.
 //
-// Each thread keeps E = 16 coefficients in registers and does R = 4 levels per
-// pass; between passes the polynomial is transposed through LDS.  Pass with base
-// bit `lo` holds positions  x = (tau >> lo) << (lo+R) | e << lo | tau & (2^lo-1).
+// Data movement.  A polynomial is owned by n/16 threads, 16 coefficients each in
+// registers.  Which coefficient sits where is a compile-time LAYOUT: every bit of the
+// position x is assigned either to one of the 4 register-index bits or to a thread-index
+// bit.  A butterfly level on position bit beta needs beta on a register bit, so the
+// transform is a sequence of
+//   - 4 levels on the current register bits,
+//   - an LDS transpose to the next layout (write at x in layout A, read at x in layout B),
+//   - for the 1-2 levels left over when 4 does not divide log2 n: a cross-lane
+//     v_permlane32_swap / v_permlane16_swap that exchanges a LANE bit with a register bit
+//     (no LDS, no barrier) instead of a fourth transpose.
+// Global loads/stores always use a layout whose lane bits are the low position bits
+// (consecutive lanes touch consecutive coefficients).
 
 constexpr int R = 4;
 constexpr int E = 1 << R;
 
-__device__ __forceinline__ int xpos(int tau, int e, int lo) {
-  return ((tau >> lo) << (lo + R)) | (e << lo) | (tau & ((1 << lo) - 1));
+struct Lay {
+  int reg[R];     // position bit held by register-index bit k
+  int thr[12];    // position bit held by thread-index bit j
+  int ntb;        // number of thread bits (log2 n - 4)
+};
+constexpr bool lay_eq(const Lay& a, const Lay& b) {
+  if (a.ntb != b.ntb) return false;
+  for (int k = 0; k < R; ++k) if (a.reg[k] != b.reg[k]) return false;
+  for (int j = 0; j < a.ntb; ++j) if (a.thr[j] != b.thr[j]) return false;
+  return true;
 }
-// one padding word per 16 keeps both the stride-16 and the stride-1 side of every
-// transpose conflict-free for ds_write_b64 / ds_read_b64
-__device__ __forceinline__ int lpad(int x) { return x + (x >> 4); }
-
-// forward (Cooley-Tukey / Harvey) butterfly: X,Y in [0,4q) -> [0,4q)
-__device__ __forceinline__ void bfly_fwd(u64& X, u64& Y, u64 w, u64 wp, u64 q, u64 q2) {
-  u64 x = csub(X, q2);
-  u64 t = shoup_lazy(Y, w, wp, q);
-  X = x + t;
-  Y = x - t + q2;
+// registers hold bits lo..lo+3, threads the remaining bits in ascending order
+constexpr Lay lay_std(int L, int lo) {
+  Lay a{};
+  a.ntb = L - R;
+  for (int k = 0; k < R; ++k) a.reg[k] = lo + k;
+  int j = 0;
+  for (int x = 0; x < L; ++x) if (x < lo || x >= lo + R) a.thr[j++] = x;
+  return a;
 }
-// inverse (Gentleman-Sande) butterfly: X,Y in [0,2q) -> [0,2q)
-__device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, u64 q, u64 q2) {
-  u64 s = X + Y;
-  u64 d = X - Y + q2;
-  X = csub(s, q2);
-  Y = shoup_lazy(d, w, wp, q);
-}
-
-template <int LO, int K0, int K1>
-__device__ __forceinline__ void fwd_levels(u64 (&v)[E], const u64* __restrict__ tw, int tau_low, u64 q, u64 q2) {
-#pragma unroll
-  for (int k = K0; k < K1; ++k) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      if (e & (1 << k)) continue;
-      const int elow = e & ((1 << k) - 1);
-      const int idx = (1 << (LO + k)) + (elow << LO) + tau_low;
-      const ulonglong2 W = *reinterpret_cast<const ulonglong2*>(tw + 2 * (size_t)idx);
-      bfly_fwd(v[e], v[e + (1 << k)], W.x, W.y, q, q2);
-    }
+// registers hold bits lo..lo+3; the `nhi` bits above them sit on lane bits lb0 (, lb1);
+// the bits below fill the other thread bits in ascending order
+constexpr Lay lay_lane_hi(int L, int lo, int nhi, int lb0, int lb1) {
+  Lay a{};
+  a.ntb = L - R;
+  for (int k = 0; k < R; ++k) a.reg[k] = lo + k;
+  int x = 0;
+  for (int j = 0; j < a.ntb; ++j) {
+    if (j == lb0) a.thr[j] = lo + R;
+    else if (nhi == 2 && j == lb1) a.thr[j] = lo + R + 1;
+    else a.thr[j] = x++;
   }
+  return a;
 }
-
-template <int LO, int K0, int K1, bool FOLD>
-__device__ __forceinline__ void inv_levels(u64 (&v)[E], const u64* __restrict__ tw, const u64* __restrict__ sc,
-                                           int tau_low, u64 q, u64 q2) {
+constexpr Lay lay_swap(Lay a, int tb, int rk) {
+  const int t = a.thr[tb];
+  a.thr[tb] = a.reg[rk];
+  a.reg[rk] = t;
+  return a;
+}
+constexpr int xreg(const Lay& a, int e) {
+  int x = 0;
+  for (int k = 0; k < R; ++k) x |= ((e >> k) & 1) << a.reg[k];
+  return x;
+}
+// position bits contributed by the thread index (runs of consecutive bits move together)
+template <Lay A>
+__device__ __forceinline__ int xthr(int tau) {
+  int x = 0;
 #pragma unroll
-  for (int k = K1 - 1; k >= K0; --k) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      if (e & (1 << k)) continue;
-      const int elow = e & ((1 << k) - 1);
-      const int idx = (1 << (LO + k)) + (elow << LO) + tau_low;
-      const ulonglong2 W = *reinterpret_cast<const ulonglong2*>(tw + 2 * (size_t)idx);
-      if (FOLD && LO + k == 0) {
-        // last level: both outputs are scaled by mhat^-1 (crt.cpp:573-579); tw[1] holds
-        // psi_2^-1 * mhat^-1 and sc holds mhat^-1, both as Shoup pairs
-        u64 s = v[e] + v[e + 1];
-        u64 d = v[e] - v[e + 1] + q2;
-        v[e] = shoup_lazy(s, sc[0], sc[1], q);
-        v[e + 1] = shoup_lazy(d, W.x, W.y, q);
-      } else {
-        bfly_inv(v[e], v[e + (1 << k)], W.x, W.y, q, q2);
-      }
-    }
+  for (int j = 0; j < A.ntb;) {
+    int len = 1;
+    while (j + len < A.ntb && A.thr[j + len] == A.thr[j] + len) ++len;
+    x |= ((tau >> j) & ((1 << len) - 1)) << A.thr[j];
+    j += len;
   }
+  return x;
 }
+// one padding word per 16: lpad(a|b) = lpad(a) + lpad(b) for bit-disjoint a, b, so the
+// register part of every LDS address is an immediate offset
+constexpr int lpad(int x) { return x + (x >> 4); }
 
-template <int LO_FROM, int LO_TO>
-__device__ __forceinline__ void transpose(u64 (&v)[E], u64* lds, int tau) {
-#pragma unroll
-  for (int e = 0; e < E; ++e) lds[lpad(xpos(tau, e, LO_FROM))] = v[e];
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = lds[lpad(xpos(tau, e, LO_TO))];
-  __syncthreads();
-}
-
-// pass schedule for n = 2^L: full passes at lo = 0, R, 2R, ...; if R does not
-// divide L the last pass sits at lo = L-R and only runs the levels still missing.
-template <int L> struct Sched {
-  static constexpr int NP = (L + R - 1) / R;
-  static constexpr int lo(int p) { return (p == NP - 1) ? (L - R) : p * R; }
-  static constexpr int k0(int p) { return (p == NP - 1) ? ((NP - 1) * R - (L - R)) : 0; }
+// Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
+struct QK {
+  u64 q, nq, q2, nq2, q4, nq4;
+  __device__ __forceinline__ explicit QK(u64 q_) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {}
 };
 
-template <int L, int P>
-__device__ __forceinline__ void fwd_from(u64 (&v)[E], u64* lds, const u64* tw, int tau, u64 q, u64 q2) {
-  if constexpr (P < Sched<L>::NP) {
-    constexpr int LO = Sched<L>::lo(P);
-    fwd_levels<LO, Sched<L>::k0(P), R>(v, tw, tau & ((1 << LO) - 1), q, q2);
-    if constexpr (P + 1 < Sched<L>::NP) {
-      transpose<LO, Sched<L>::lo(P + 1)>(v, lds, tau);
-      fwd_from<L, P + 1>(v, lds, tw, tau, q, q2);
-    }
+// Two arithmetic flavours, chosen per plan on the host:
+//  APPROX (every q_t < 2^61): Shoup products with the 9-multiply approximate quotient
+//    (shoup_acc, result in [0,4q)); forward values live in [0,8q), inverse values in [0,4q).
+//  exact  (2^61 <= q_t < 2^62): 10-multiply exact quotient, Harvey's [0,4q) / [0,2q) ranges.
+
+// forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
+template <bool APPROX>
+__device__ __forceinline__ void bfly_fwd(u64& X, u64& Y, u64 w, u64 wp, const QK& k) {
+  if constexpr (APPROX) {
+    const u64 x = csubn(X, k.nq4);                    // [0,8q) -> [0,4q)
+    const u64 xn = shoup_acc(Y, w, wp, k.nq, x);      // x + t, t in [0,4q)
+    const u64 z = shl1_add64(x, k.q4);                // 2x + 4q
+    X = xn;
+    Y = z - xn;                                       // x - t + 4q
+  } else {
+    const u64 x = csub(X, k.q2);
+    const u64 t = shoup_lazy(Y, w, wp, k.q);
+    X = x + t;
+    Y = x - t + k.q2;
   }
 }
-template <int L, int P>
-__device__ __forceinline__ void inv_from(u64 (&v)[E], u64* lds, const u64* tw, const u64* sc, int tau, u64 q, u64 q2) {
-  if constexpr (P >= 0) {
-    constexpr int LO = Sched<L>::lo(P);
-    inv_levels<LO, Sched<L>::k0(P), R, true>(v, tw, sc, tau & ((1 << LO) - 1), q, q2);
-    if constexpr (P > 0) {
-      transpose<LO, Sched<L>::lo(P - 1)>(v, lds, tau);
-      inv_from<L, P - 1>(v, lds, tw, sc, tau, q, q2);
+// inverse (Gentleman-Sande) butterfly:  X' = X + Y,  Y' = (X - Y) * w
+template <bool APPROX>
+__device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, const QK& k) {
+  if constexpr (APPROX) {
+    const u64 s = add64(X, Y);                        // [0,8q)
+    const u64 d = add64(X, k.q4) - Y;                 // (0,8q)
+    X = csubn(s, k.nq4);
+    Y = shoup_acc(d, w, wp, k.nq, 0);
+  } else {
+    const u64 s = X + Y;
+    const u64 d = X - Y + k.q2;
+    X = csub(s, k.q2);
+    Y = shoup_lazy(d, w, wp, k.q);
+  }
+}
+// last inverse level: both outputs additionally scaled by mhat^-1 (crt.cpp:573-579).
+// (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
+template <bool APPROX>
+__device__ __forceinline__ void bfly_inv_last(u64& X, u64& Y, u64 w, u64 wp, u64 s0, u64 s1, const QK& k) {
+  if constexpr (APPROX) {
+    const u64 s = add64(X, Y);
+    const u64 d = add64(X, k.q4) - Y;
+    X = shoup_acc(s, s0, s1, k.nq, 0);
+    Y = shoup_acc(d, w, wp, k.nq, 0);
+  } else {
+    const u64 s = X + Y;
+    const u64 d = X - Y + k.q2;
+    X = shoup_lazy(s, s0, s1, k.q);
+    Y = shoup_lazy(d, w, wp, k.q);
+  }
+}
+template <bool APPROX> __device__ __forceinline__ u64 canon_fwd(u64 v, const QK& k) {
+  if constexpr (APPROX) v = csubn(v, k.nq4);
+  return csubn(csubn(v, k.nq2), k.nq);
+}
+template <bool APPROX> __device__ __forceinline__ u64 canon_inv(u64 v, const QK& k) {
+  if constexpr (APPROX) v = csubn(v, k.nq2);
+  return csubn(v, k.nq);
+}
+
+// Global memory goes through buffer descriptors: address = base (SGPRs) + one 32-bit
+// per-lane offset + a wave-uniform offset, so no 64-bit address lives in VGPRs.
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u64& w, u64& wp) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tw, voff, const_idx * 16u, 0);
+  w = ((u64)r.y << 32) | r.x;
+  wp = ((u64)r.w << 32) | r.z;
+}
+__device__ __forceinline__ u64 load_u64(rsrc_t r, u32 voff, u32 soff) {
+  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return ((u64)x.y << 32) | x.x;
+}
+__device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val) {
+  u32x2 x;
+  x.x = (u32)val; x.y = (u32)(val >> 32);
+  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+}
+
+struct TwCtx {
+  rsrc_t fwd, inv;
+  u32 comp;        // byte offset of this RNS component's table
+  u64 sc0, sc1;    // Shoup pair of mhat^-1
+};
+
+// ---- twiddles: fetched a whole register pass ahead ------------------------------------
+// Level on register bit K of layout A: butterflies pair e and e|1<<K; the twiddle index is
+// x mod 2^beta (beta = A.reg[K]), whose register part is a compile-time constant.  Threads
+// issue the (deduplicated) loads for ALL levels of a pass before the LDS transpose that
+// precedes it, so L2 latency overlaps the exchange and the barrier.
+constexpr int tw_cidx(const Lay& a, int k, int e) {
+  const int beta = a.reg[k];
+  return (1 << beta) + (xreg(a, e) & ((1 << beta) - 1));
+}
+// ordinal (0..7) of the first butterfly of level k that uses the same twiddle as butterfly e
+constexpr int tw_slot(const Lay& a, int k, int e) {
+  int ord = 0;
+  for (int f = 0; f < E; ++f) {
+    if (f & (1 << k)) continue;
+    if (tw_cidx(a, k, f) == tw_cidx(a, k, e)) return ord;
+    ++ord;
+  }
+  return 0;
+}
+struct LevelTw { u64 w[8], wp[8]; };
+
+template <bool INV, Lay A, int K>
+__device__ __forceinline__ void tw_fetch(LevelTw& t, const TwCtx& tw, int xt) {
+  constexpr int beta = A.reg[K];
+  const u32 voff = tw.comp + (u32)(xt & ((1 << beta) - 1)) * 16u;
+  int ord = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (e & (1 << K)) continue;
+    if (tw_slot(A, K, e) == ord) load_tw(INV ? tw.inv : tw.fwd, voff, (u32)tw_cidx(A, K, e), t.w[ord], t.wp[ord]);
+    ++ord;
+  }
+}
+template <bool APPROX, bool INV, Lay A, int K>
+__device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx& tw, const QK& qk) {
+  constexpr int beta = A.reg[K];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (e & (1 << K)) continue;
+    const int s = tw_slot(A, K, e);
+    if constexpr (!INV) bfly_fwd<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+    else if constexpr (beta == 0) bfly_inv_last<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
+    else bfly_inv<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+  }
+}
+
+// exchange lane bit TB (4 or 5) with register bit RK: 16 v_permlane*_swap, no LDS
+template <int TB, int RK>
+__device__ __forceinline__ void lane_swap(u64 (&v)[E]) {
+  static_assert(TB == 4 || TB == 5, "only lane bits 4 and 5 have swap instructions");
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (e & (1 << RK)) continue;
+    const int f = e | (1 << RK);
+    u32x2 lo, hi;
+    if constexpr (TB == 5) {
+      lo = __builtin_amdgcn_permlane32_swap((u32)v[e], (u32)v[f], false, false);
+      hi = __builtin_amdgcn_permlane32_swap((u32)(v[e] >> 32), (u32)(v[f] >> 32), false, false);
+    } else {
+      lo = __builtin_amdgcn_permlane16_swap((u32)v[e], (u32)v[f], false, false);
+      hi = __builtin_amdgcn_permlane16_swap((u32)(v[e] >> 32), (u32)(v[f] >> 32), false, false);
+    }
+    v[e] = ((u64)hi.x << 32) | lo.x;
+    v[f] = ((u64)hi.y << 32) | lo.y;
+  }
+}
+
+// LDS transpose A -> B, split so that independent work can sit between the halves.
+// The barrier that protects the previous exchange's reads comes FIRST (by then every
+// wave has long finished them), not right after the reads.
+template <Lay A, Lay B>
+__device__ __forceinline__ void transpose_put(u64 (&v)[E], u64* lds, int tau) {
+  if constexpr (!lay_eq(A, B)) {
+    __syncthreads();
+    u64* wp = lds + lpad(xthr<A>(tau));
+#pragma unroll
+    for (int e = 0; e < E; ++e) wp[lpad(xreg(A, e))] = v[e];
+  }
+}
+template <Lay A, Lay B>
+__device__ __forceinline__ void transpose_get(u64 (&v)[E], u64* lds, int tau) {
+  if constexpr (!lay_eq(A, B)) {
+    __syncthreads();
+    const u64* rp = lds + lpad(xthr<B>(tau));
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = rp[lpad(xreg(B, e))];
+  }
+}
+
+// compile-time schedule for n = 2^L
+template <int L> struct Sched {
+  static constexpr int NTB = L - R;
+  static constexpr int NFULL = L / R, LEFT = L % R;
+  // leftover levels via lane swaps when the needed lane bits belong to this polynomial
+  static constexpr bool SWAPS = LEFT > 0 && LEFT <= 2 && (LEFT == 2 ? NTB >= 6 : NTB >= 5);
+  static constexpr int LB0 = (LEFT == 2) ? 4 : (NTB >= 6 ? 5 : 4);
+  static constexpr int LB1 = 5;
+  static constexpr int NPASS = NFULL + ((LEFT > 0 && !SWAPS) ? 1 : 0);   // register passes through LDS
+  static constexpr Lay pass(int p) {
+    if (p < NFULL - 1) return lay_std(L, p * R);
+    if (p == NFULL - 1) return SWAPS ? lay_lane_hi(L, p * R, LEFT, LB0, LB1) : lay_std(L, p * R);
+    return lay_std(L, L - R);                                             // overlapping last pass
+  }
+  // first register bit with work in pass p (the overlapping pass only runs the missing top levels)
+  static constexpr int k0(int p) { return p < NFULL ? 0 : R - LEFT; }
+  static constexpr Lay io() { return lay_std(L, L - R); }                 // lanes = low position bits
+  static constexpr Lay swap1() { return lay_swap(pass(NFULL - 1), LB0, 3); }
+  static constexpr Lay swap2() { return lay_swap(swap1(), LB1, 2); }
+  static constexpr Lay final_layout() { return SWAPS ? (LEFT == 2 ? swap2() : swap1()) : pass(NPASS - 1); }
+};
+
+// forward: data arrives in layout PREV (already in registers)
+template <bool APPROX, int L, int P, Lay PREV>
+__device__ __forceinline__ void fwd_passes(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+  using S = Sched<L>;
+  if constexpr (P < S::NPASS) {
+    constexpr Lay A = S::pass(P);
+    constexpr int K0 = S::k0(P);
+    const int xt = xthr<A>(tau);
+    transpose_put<PREV, A>(v, lds, tau);
+    LevelTw t0, t1, t2, t3;
+    if constexpr (K0 <= 0) tw_fetch<false, A, 0>(t0, tw, xt);
+    if constexpr (K0 <= 1) tw_fetch<false, A, 1>(t1, tw, xt);
+    if constexpr (K0 <= 2) tw_fetch<false, A, 2>(t2, tw, xt);
+    tw_fetch<false, A, 3>(t3, tw, xt);
+    transpose_get<PREV, A>(v, lds, tau);
+    if constexpr (K0 <= 0) level<APPROX, false, A, 0>(v, t0, tw, qk);
+    if constexpr (K0 <= 1) level<APPROX, false, A, 1>(v, t1, tw, qk);
+    if constexpr (K0 <= 2) level<APPROX, false, A, 2>(v, t2, tw, qk);
+    level<APPROX, false, A, 3>(v, t3, tw, qk);
+    fwd_passes<APPROX, L, P + 1, A>(v, lds, tw, tau, qk);
+  }
+}
+template <bool APPROX, int L, Lay PREV>
+__device__ __forceinline__ void fwd_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+  using S = Sched<L>;
+  fwd_passes<APPROX, L, 0, PREV>(v, lds, tw, tau, qk);
+  if constexpr (S::SWAPS) {
+    constexpr Lay A1 = S::swap1();
+    LevelTw t;
+    tw_fetch<false, A1, 3>(t, tw, xthr<A1>(tau));
+    lane_swap<S::LB0, 3>(v);
+    level<APPROX, false, A1, 3>(v, t, tw, qk);
+    if constexpr (S::LEFT == 2) {
+      constexpr Lay A2 = S::swap2();
+      LevelTw u;
+      tw_fetch<false, A2, 2>(u, tw, xthr<A2>(tau));
+      lane_swap<S::LB1, 2>(v);
+      level<APPROX, false, A2, 2>(v, u, tw, qk);
     }
   }
 }
 
+// inverse: data arrives in layout PREV; leaves in layout pass(0)
+template <bool APPROX, int L, int P, Lay PREV>
+__device__ __forceinline__ void inv_passes(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+  using S = Sched<L>;
+  if constexpr (P >= 0) {
+    constexpr Lay A = S::pass(P);
+    constexpr int K0 = S::k0(P);
+    const int xt = xthr<A>(tau);
+    transpose_put<PREV, A>(v, lds, tau);
+    LevelTw t0, t1, t2, t3;
+    tw_fetch<true, A, 3>(t3, tw, xt);
+    if constexpr (K0 <= 2) tw_fetch<true, A, 2>(t2, tw, xt);
+    if constexpr (K0 <= 1) tw_fetch<true, A, 1>(t1, tw, xt);
+    if constexpr (K0 <= 0) tw_fetch<true, A, 0>(t0, tw, xt);
+    transpose_get<PREV, A>(v, lds, tau);
+    level<APPROX, true, A, 3>(v, t3, tw, qk);
+    if constexpr (K0 <= 2) level<APPROX, true, A, 2>(v, t2, tw, qk);
+    if constexpr (K0 <= 1) level<APPROX, true, A, 1>(v, t1, tw, qk);
+    if constexpr (K0 <= 0) level<APPROX, true, A, 0>(v, t0, tw, qk);
+    inv_passes<APPROX, L, P - 1, A>(v, lds, tw, tau, qk);
+  }
+}
+// data arrives in Sched<L>::final_layout()
+template <bool APPROX, int L>
+__device__ __forceinline__ void inv_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+  using S = Sched<L>;
+  if constexpr (S::SWAPS) {
+    constexpr Lay A1 = S::swap1();
+    if constexpr (S::LEFT == 2) {
+      constexpr Lay A2 = S::swap2();
+      LevelTw u;
+      tw_fetch<true, A2, 2>(u, tw, xthr<A2>(tau));
+      level<APPROX, true, A2, 2>(v, u, tw, qk);
+      lane_swap<S::LB1, 2>(v);
+    }
+    LevelTw t;
+    tw_fetch<true, A1, 3>(t, tw, xthr<A1>(tau));
+    level<APPROX, true, A1, 3>(v, t, tw, qk);
+    lane_swap<S::LB0, 3>(v);
+  }
+  inv_passes<APPROX, L, S::NPASS - 1, S::pass(S::NPASS - 1)>(v, lds, tw, tau, qk);
+}
+
+constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
+
 // MODE 0: crt in place, 1: crtInv in place, 2: c = crtInv(crt(a) * crt(b))
-template <int L, int MODE>
-__global__ void __launch_bounds__((1 << (L - R)) * ((1 << (L - R)) >= 256 ? 1 : 256 / (1 << (L - R))))
-k_pow2(i64* __restrict__ y, const i64* __restrict__ a_in, const i64* __restrict__ b_in, i64 B, int T,
+template <int L, int MODE, bool APPROX>
+__global__ void __launch_bounds__(pow2_threads(L), 4)
+k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
        const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv, const u64* __restrict__ scale,
        const ModCtx* __restrict__ mod, int xcd_map) {
+  using S = Sched<L>;
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);                  // threads per polynomial
   constexpr int PPW = NT >= 256 ? 1 : 256 / NT;     // polynomials per workgroup
@@ -158,59 +419,87 @@ k_pow2(i64* __restrict__ y, const i64* __restrict__ a_in, const i64* __restrict_
   // work item -> (b, t); with xcd_map the T components of one polynomial land on
   // workgroups that share an XCD (equal blockIdx % 8) so its cache lines are
   // fetched from HBM once.  Placement only affects speed.
-  i64 item = (i64)blockIdx.x * PPW + threadIdx.x / NT;
-  i64 b; int t;
-  if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; }
-  else { b = item / T; t = (int)(item % T); }
-  const bool live = b < B;          // tail workgroup of a packed launch
-  if (!live) { b = B - 1; }         // keep every thread in the barriers; stores are masked
+  const i64 item0 = (i64)blockIdx.x * PPW;             // wave-uniform
+  const int slot = (PPW == 1) ? 0 : (int)(threadIdx.x / NT);
+  const i64 item = item0 + slot;
+  i64 b, b0; int t;
+  if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
+  else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
 
   const ModCtx mc = mod[t];
-  const u64 q = mc.q, q2 = 2 * mc.q;
-  const u64* twf = tw_fwd + (size_t)t * n * 2;
-  const u64* twi = tw_inv + (size_t)t * n * 2;
-  const u64* sc = scale + (size_t)t * 2;
-  const size_t base = (size_t)b * n;
+  const QK qk(mc.q);
+  // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
+  // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
+  // stores are dropped by the hardware range check.
+  const u64 win = (u64)(B - b0) * n * T * 8;
+  const u32 wbytes = win > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)win;
+  const size_t wbase = (size_t)b0 * n * T;
+  const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + wbase), 0, wbytes, 0x00020000);
+  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
+  TwCtx tw;
+  tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * 16u, 0x00020000);
+  tw.inv = __builtin_amdgcn_make_buffer_rsrc((void*)tw_inv, 0, (u32)T * n * 16u, 0x00020000);
+  tw.comp = (u32)t * (u32)n * 16u;
+  tw.sc0 = scale[(size_t)t * 2];
+  tw.sc1 = scale[(size_t)t * 2 + 1];
+
+  constexpr Lay LIO = S::io();              // global I/O of powerful-basis data
+  constexpr Lay LP0 = S::pass(0);
+  constexpr Lay LFIN = S::final_layout();   // where the forward transform leaves the CRT coefficients
+  const u32 uT8 = (u32)T * 8u;
+  const u32 pofs = ((u32)(b - b0) * (u32)n * (u32)T + (u32)t) * 8u;       // this polynomial inside the window
+  const u32 off_io = pofs + (u32)xthr<LIO>(tau) * uT8;
+  const u32 off_fin = pofs + (u32)xthr<LFIN>(tau) * uT8;
 
   u64 v[E];
   if constexpr (MODE == 0 || MODE == 2) {
-    const i64* src = (MODE == 2) ? a_in : y;
+    const rsrc_t src = (MODE == 2) ? ra : ry;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in(src[(base + xpos(tau, e, 0)) * T + t], q);
-    fwd_from<L, 0>(v, lds, twf, tau, q, q2);
+    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(src, off_io, (u32)xreg(LIO, e) * uT8), qk.q);
+    fwd_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
   }
   if constexpr (MODE == 2) {
-    u64 va[E];
+    // a-hat does not fit in registers next to b's transform at 4 waves/SIMD, and LDS is
+    // full: park it (canonical) in the output rows this workgroup owns — each thread
+    // re-reads exactly the words it wrote, normally still in L2.  The host passes the
+    // operand that aliases c (if any) as `a`, so nothing unread is overwritten.
 #pragma unroll
-    for (int e = 0; e < E; ++e) va[e] = csub(csub(v[e], q2), q);
-    __syncthreads();
+    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8, canon_fwd<APPROX>(v[e], qk));
+    __builtin_amdgcn_sched_barrier(0);
+    const bool square = (a_in == b_in);
+    if (!square) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in(b_in[(base + xpos(tau, e, 0)) * T + t], q);
-    fwd_from<L, 0>(v, lds, twf, tau, q, q2);
+      for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(rb, off_io, (u32)xreg(LIO, e) * uT8), qk.q);
+      fwd_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // a-hat is canonical, b-hat may stay lazy (< 8q): the product is still < q * 2^64
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = mulmod(va[e], csub(csub(v[e], q2), q), mc);
-    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      const u64 ah = load_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8);
+      const u64 bh = square ? ah : (APPROX ? v[e] : canon_fwd<APPROX>(v[e], qk));
+      v[e] = mulmod(ah, bh, mc);
+      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  constexpr int LOL = Sched<L>::lo(Sched<L>::NP - 1);   // layout after the forward transform
   if constexpr (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in(y[(base + xpos(tau, e, LOL)) * T + t], q);
+    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8), qk.q);
   }
   if constexpr (MODE == 0) {
-    if (live) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) y[(base + xpos(tau, e, LOL)) * T + t] = (i64)csub(csub(v[e], q2), q);
-    }
+    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8, canon_fwd<APPROX>(v[e], qk));
   } else {
-    inv_from<L, Sched<L>::NP - 1>(v, lds, twi, sc, tau, q, q2);
-    if (live) {
+    inv_transform<APPROX, L>(v, lds, tw, tau, qk);
+    transpose_put<LP0, LIO>(v, lds, tau);
+    transpose_get<LP0, LIO>(v, lds, tau);
 #pragma unroll
-      for (int e = 0; e < E; ++e) y[(base + xpos(tau, e, 0)) * T + t] = (i64)csub(v[e], q);
-    }
+    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)xreg(LIO, e) * uT8, canon_inv<APPROX>(v[e], qk));
   }
 }
 
-template <int L, int MODE>
+template <int L, int MODE, bool APPROX>
 static hipError_t launch_pow2_L(const Pow2Launch& a) {
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);
@@ -223,39 +512,39 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
   if (grid == 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, APPROX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_pow2<L, MODE>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
+  hipLaunchKernelGGL((k_pow2<L, MODE, APPROX>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
                      a.y, a.a, a.b, a.B, a.T, a.tw_fwd, a.tw_inv, a.scale, a.mod, xcd_map);
   return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, bool APPROX>
 static hipError_t launch_pow2_mode(const Pow2Launch& a) {
   switch (a.L) {
-    case 4: return launch_pow2_L<4, MODE>(a);
-    case 5: return launch_pow2_L<5, MODE>(a);
-    case 6: return launch_pow2_L<6, MODE>(a);
-    case 7: return launch_pow2_L<7, MODE>(a);
-    case 8: return launch_pow2_L<8, MODE>(a);
-    case 9: return launch_pow2_L<9, MODE>(a);
-    case 10: return launch_pow2_L<10, MODE>(a);
-    case 11: return launch_pow2_L<11, MODE>(a);
-    case 12: return launch_pow2_L<12, MODE>(a);
-    case 13: return launch_pow2_L<13, MODE>(a);
-    case 14: return launch_pow2_L<14, MODE>(a);
+    case 4: return launch_pow2_L<4, MODE, APPROX>(a);
+    case 5: return launch_pow2_L<5, MODE, APPROX>(a);
+    case 6: return launch_pow2_L<6, MODE, APPROX>(a);
+    case 7: return launch_pow2_L<7, MODE, APPROX>(a);
+    case 8: return launch_pow2_L<8, MODE, APPROX>(a);
+    case 9: return launch_pow2_L<9, MODE, APPROX>(a);
+    case 10: return launch_pow2_L<10, MODE, APPROX>(a);
+    case 11: return launch_pow2_L<11, MODE, APPROX>(a);
+    case 12: return launch_pow2_L<12, MODE, APPROX>(a);
+    case 13: return launch_pow2_L<13, MODE, APPROX>(a);
+    case 14: return launch_pow2_L<14, MODE, APPROX>(a);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (mode) {
-    case 0: return launch_pow2_mode<0>(a);
-    case 1: return launch_pow2_mode<1>(a);
-    case 2: return launch_pow2_mode<2>(a);
+    case 0: return a.approx ? launch_pow2_mode<0, true>(a) : launch_pow2_mode<0, false>(a);
+    case 1: return a.approx ? launch_pow2_mode<1, true>(a) : launch_pow2_mode<1, false>(a);
+    case 2: return a.approx ? launch_pow2_mode<2, true>(a) : launch_pow2_mode<2, false>(a);
     default: return hipErrorInvalidValue;
   }
 }

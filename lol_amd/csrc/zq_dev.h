@@ -77,6 +77,54 @@ LH_D u64 shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
   return w * y - Q * q;
 }
 
+// ---- hand-scheduled pieces for the NTT inner loop --------------------------------
+// v_mad_u64_u32 (32x32+64 -> 64) and v_lshl_add_u64 are the two 64-bit integer
+// workhorses on gfx950; spelling them out keeps hipcc from splitting the chains into
+// v_mul_lo_u32 + carry adds (each carry add needs a 2-wait-state hazard nop here).
+LH_D u64 mad64(u32 a, u32 b, u64 c) {
+  u64 d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+LH_D u64 add64(u64 a, u64 b) {
+  u64 d;
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+LH_D u64 shl1_add64(u64 a, u64 b) {
+  u64 d;
+  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+LH_D u32 lo32(u64 x) { return (u32)x; }
+LH_D u32 hi32(u64 x) { return (u32)(x >> 32); }
+
+// x + negm if that is non-negative else x, i.e. csub(x, m) with negm = -m (mod 2^64);
+// requires |x - m| < 2^63
+LH_D u64 csubn(u64 x, u64 negm) {
+  u64 t = add64(x, negm);
+  return ((int)hi32(t) < 0) ? x : t;
+}
+
+// init + w*y - Q*q (mod 2^64) with an APPROXIMATE quotient
+//   Q = wp.hi*y.hi + hi32(wp.hi*y.lo) + hi32(wp.lo*y.hi)  in {floor(wp*y/2^64) - 2 .. same}
+// so (result - init) = w*y mod q + {0..3}*q  in [0, 4q) for any 64-bit y.  7 mads + 2
+// mul_hi instead of the 10 multiplies of the exact form; nq = -q (mod 2^64).
+LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
+  const u32 ah = __umulhi(hi32(wp), lo32(y));
+  const u32 bh = __umulhi(lo32(wp), hi32(y));
+  const u64 Q = mad64(bh, 1u, mad64(hi32(wp), hi32(y), (u64)ah));
+  u64 t = mad64(lo32(w), lo32(y), init);
+  t = mad64(lo32(Q), lo32(nq), t);
+  u64 h = mad64(lo32(w), hi32(y), 0);
+  h = mad64(hi32(w), lo32(y), h);
+  h = mad64(lo32(Q), hi32(nq), h);
+  h = mad64(hi32(Q), lo32(nq), h);
+  u32 th;
+  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  return ((u64)th << 32) | lo32(t);
+}
+
 // remainder of the 128-bit value (u1:u0) by c.q, requires (u1:u0) < q * 2^64
 LH_D u64 rem128(u64 x1, u64 x0, const ModCtx& c) {
   // normalise
