@@ -54,10 +54,23 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
+def _usable_cores() -> int:
+    """Cores this job may really use: affinity, capped by the cgroup CPU quota (the GPU box
+    exposes 64 CPUs but grants a 1-GPU job a 16-core share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(q: int, budget_s: float = 12.0):
     from oracle.oracle import CTREF_SO
     kind = "reference" if os.path.exists(CTREF_SO) else "port"
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = _usable_cores()
     # calibrate one poly-mul on one core, then size the sample to the budget
     t1 = _cpu_worker((q, 3, 1, kind)) / 3
     count = max(4, int(budget_s / max(t1, 1e-4)))

@@ -47,6 +47,16 @@ namespace lolhip {
 constexpr int R = 4;
 constexpr int E = 1 << R;
 
+// Diagnostic build (-DLOLHIP_STAMPS): per-wave s_memtime stamps at phase boundaries, written
+// to a side buffer nobody else reads.  Never enabled in the shipped library.
+#ifdef LOLHIP_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define LH_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (g_stamp_buf && (threadIdx.x & 63) == 0) g_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (i)] = t_; } while (0)
+#else
+#define LH_STAMP(i) do {} while (0)
+#endif
+
 struct Lay {
   int reg[R];     // position bit held by register-index bit k
   int thr[12];    // position bit held by thread-index bit j
@@ -92,19 +102,37 @@ constexpr int xreg(const Lay& a, int e) {
   for (int k = 0; k < R; ++k) x |= ((e >> k) & 1) << a.reg[k];
   return x;
 }
-// position bits contributed by the thread index (runs of consecutive bits move together)
-template <Lay A>
-__device__ __forceinline__ int xthr(int tau) {
-  int x = 0;
-#pragma unroll
-  for (int j = 0; j < A.ntb;) {
+// position bits contributed by the thread index (runs of consecutive bits move together).
+// The run decomposition is forced through a constexpr object: left as a loop over the
+// template-parameter object, hipcc emits a RUNTIME loop of dependent global loads.
+struct LayRuns { int n; int src[12]; int len[12]; int dst[12]; };
+constexpr LayRuns lay_runs(const Lay& a) {
+  LayRuns r{};
+  for (int j = 0; j < a.ntb;) {
     int len = 1;
-    while (j + len < A.ntb && A.thr[j + len] == A.thr[j] + len) ++len;
-    x |= ((tau >> j) & ((1 << len) - 1)) << A.thr[j];
+    while (j + len < a.ntb && a.thr[j + len] == a.thr[j] + len) ++len;
+    r.src[r.n] = j; r.len[r.n] = len; r.dst[r.n] = a.thr[j];
+    ++r.n;
     j += len;
   }
-  return x;
+  return r;
 }
+template <Lay A, int I>
+__device__ __forceinline__ int xthr_run(int tau) {
+  constexpr LayRuns r = lay_runs(A);
+  if constexpr (I < r.n) return (((tau >> r.src[I]) & ((1 << r.len[I]) - 1)) << r.dst[I]) | xthr_run<A, I + 1>(tau);
+  else return 0;
+}
+template <Lay A>
+__device__ __forceinline__ int xthr(int tau) { return xthr_run<A, 0>(tau); }
+
+// per-layout compile-time tables (register part of x, twiddle index and slot per butterfly)
+template <Lay A> struct LayTab {
+  int xr[E];
+  constexpr LayTab() : xr{} { for (int e = 0; e < E; ++e) xr[e] = xreg(A, e); }
+};
+template <Lay A> inline constexpr LayTab<A> lay_tab{};
+
 // one padding word per 16: lpad(a|b) = lpad(a) + lpad(b) for bit-disjoint a, b, so the
 // register part of every LDS address is an immediate offset
 constexpr int lpad(int x) { return x + (x >> 4); }
@@ -197,11 +225,27 @@ __device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val)
   __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 
+// Where a level's twiddles come from:
+//  * index bits all on registers (the thread part of x mod 2^beta is empty): wave-uniform,
+//    read with SCALAR loads — no texture-path traffic at all;
+//  * beta <= 8: from a per-workgroup LDS copy of table entries [16, 512) (levels 5..9) —
+//    the texture path costs 16 clk per 1 KiB wave-load even when 64 lanes hit 16 addresses,
+//    and at 60 such loads per wave it, not the ALU, was bounding the transform;
+//  * otherwise (the top levels, whose tables are 8 KiB..64 KiB): buffer loads, L2-served.
+constexpr int TWL_LO = 16, TWL_HI = 512;              // LDS-resident table entries [lo, hi)
+constexpr int twl_words(int n) { return n > TWL_LO ? 2 * ((n < TWL_HI ? n : TWL_HI) - TWL_LO) : 0; }
+
 struct TwCtx {
   rsrc_t fwd, inv;
-  u32 comp;        // byte offset of this RNS component's table
-  u64 sc0, sc1;    // Shoup pair of mhat^-1
+  const u64 *pf, *pi;   // this component's tables as plain pointers (scalar loads)
+  const u64* lds_tw;    // LDS copy of entries [16,512) of the table currently in use
+  u32 comp;             // byte offset of this RNS component's table
+  u64 sc0, sc1;         // Shoup pair of mhat^-1
 };
+template <Lay A, int K> constexpr bool tw_uniform() {
+  for (int j = 0; j < A.ntb; ++j) if (A.thr[j] < A.reg[K]) return false;
+  return true;
+}
 
 // ---- twiddles: fetched a whole register pass ahead ------------------------------------
 // Level on register bit K of layout A: butterflies pair e and e|1<<K; the twiddle index is
@@ -222,27 +266,62 @@ constexpr int tw_slot(const Lay& a, int k, int e) {
   }
   return 0;
 }
+template <Lay A, int K> struct LevelTab {
+  int cidx[E], slot[E];
+  constexpr LevelTab() : cidx{}, slot{} { for (int e = 0; e < E; ++e) { cidx[e] = tw_cidx(A, K, e); slot[e] = tw_slot(A, K, e); } }
+};
+template <Lay A, int K> inline constexpr LevelTab<A, K> level_tab{};
 struct LevelTw { u64 w[8], wp[8]; };
 
 template <bool INV, Lay A, int K>
 __device__ __forceinline__ void tw_fetch(LevelTw& t, const TwCtx& tw, int xt) {
   constexpr int beta = A.reg[K];
+#ifdef LOLHIP_ABL_NO_TW       // ablation: no twiddle traffic
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { t.w[s] = tw.sc0 + s; t.wp[s] = tw.sc1 + K; }
+  return;
+#endif
   const u32 voff = tw.comp + (u32)(xt & ((1 << beta) - 1)) * 16u;
+  const u64* sp = INV ? tw.pi : tw.pf;
   int ord = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
-    if (tw_slot(A, K, e) == ord) load_tw(INV ? tw.inv : tw.fwd, voff, (u32)tw_cidx(A, K, e), t.w[ord], t.wp[ord]);
+    if (level_tab<A, K>.slot[e] == ord) {
+      const int cidx = level_tab<A, K>.cidx[e];
+      if constexpr (tw_uniform<A, K>()) {
+        t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
+      } else if constexpr ((2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
+        const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1))));
+        t.w[ord] = r.x; t.wp[ord] = r.y;
+      } else {
+        load_tw(INV ? tw.inv : tw.fwd, voff, (u32)cidx, t.w[ord], t.wp[ord]);
+      }
+    }
     ++ord;
+  }
+}
+// copy entries [16, 512) of one component's table into LDS (NT threads of one polynomial)
+template <int NT>
+__device__ __forceinline__ void tw_fill_lds(u64* dst, rsrc_t src, u32 comp, int n, int tau) {
+  const int cnt = (n < TWL_HI ? n : TWL_HI) - TWL_LO;
+  for (int i = tau; i < cnt; i += NT) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(src, comp + (u32)(TWL_LO + i) * 16u, 0, 0);
+    *reinterpret_cast<u32x4*>(dst + 2 * i) = r;
   }
 }
 template <bool APPROX, bool INV, Lay A, int K>
 __device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx& tw, const QK& qk) {
   constexpr int beta = A.reg[K];
+#ifdef LOLHIP_ABL_NO_BFLY     // ablation: keep the twiddles live, skip the arithmetic
+#pragma unroll
+  for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(t.w[s]), "v"(t.wp[s]));
+  return;
+#endif
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
-    const int s = tw_slot(A, K, e);
+    const int s = level_tab<A, K>.slot[e];
     if constexpr (!INV) bfly_fwd<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
     else if constexpr (beta == 0) bfly_inv_last<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
     else bfly_inv<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
@@ -270,133 +349,191 @@ __device__ __forceinline__ void lane_swap(u64 (&v)[E]) {
   }
 }
 
-// LDS transpose A -> B, split so that independent work can sit between the halves.
-// The barrier that protects the previous exchange's reads comes FIRST (by then every
-// wave has long finished them), not right after the reads.
-template <Lay A, Lay B>
+// LDS transpose A -> B, split so that independent work (twiddle fetches) sits between the
+// halves.  WAVE-LOCAL transposes (both layouts keep a wave inside its own 1024-coefficient
+// block) need no s_barrier at all: a wave's LDS instructions execute in order.  Only the one
+// transpose per transform that crosses waves pays two workgroup barriers; the one protecting
+// the previous reads comes FIRST, when every wave has long finished them.
+template <Lay A, Lay B, bool CROSS_WAVE>
 __device__ __forceinline__ void transpose_put(u64 (&v)[E], u64* lds, int tau) {
+#ifdef LOLHIP_ABL_NO_XPOSE
+  return;
+#endif
   if constexpr (!lay_eq(A, B)) {
-    __syncthreads();
+    if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     u64* wp = lds + lpad(xthr<A>(tau));
 #pragma unroll
-    for (int e = 0; e < E; ++e) wp[lpad(xreg(A, e))] = v[e];
+    for (int e = 0; e < E; ++e) wp[lpad(lay_tab<A>.xr[e])] = v[e];
   }
 }
-template <Lay A, Lay B>
+template <Lay A, Lay B, bool CROSS_WAVE>
 __device__ __forceinline__ void transpose_get(u64 (&v)[E], u64* lds, int tau) {
+#ifdef LOLHIP_ABL_NO_XPOSE
+  return;
+#endif
   if constexpr (!lay_eq(A, B)) {
-    __syncthreads();
+    if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     const u64* rp = lds + lpad(xthr<B>(tau));
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = rp[lpad(xreg(B, e))];
+    for (int e = 0; e < E; ++e) v[e] = rp[lpad(lay_tab<B>.xr[e])];
   }
 }
 
-// compile-time schedule for n = 2^L
+// layout with explicit register bits; thread bits listed lowest first
+constexpr Lay lay_make(int L, int r0, int r1, int r2, int r3, const int* thr_bits) {
+  Lay a{};
+  a.ntb = L - R;
+  a.reg[0] = r0; a.reg[1] = r1; a.reg[2] = r2; a.reg[3] = r3;
+  for (int j = 0; j < a.ntb; ++j) a.thr[j] = thr_bits[j];
+  return a;
+}
+
+// Compile-time schedule for n = 2^L.  LW = min(L,10) levels run WAVE-LOCALLY (a wave owns a
+// block of 1024 consecutive coefficients, or 2^(10-L) whole polynomials when L < 10):
+//   W0: registers = bits 0..3                      -> levels 1..4
+//   W1: registers = bits 4..7, lane bits 4,5 = 8,9  -> levels 5..8, lane swaps -> levels 9, 10
+//       (for L < 8 an overlapping window of the top four bits instead)
+// and the remaining L-10 levels after ONE cross-wave transpose into
+//   G:  registers = bits L-4..L-1                   -> levels 11..L
+// G is also the coalesced global-memory layout (consecutive lanes = consecutive coefficients).
 template <int L> struct Sched {
   static constexpr int NTB = L - R;
-  static constexpr int NFULL = L / R, LEFT = L % R;
-  // leftover levels via lane swaps when the needed lane bits belong to this polynomial
-  static constexpr bool SWAPS = LEFT > 0 && LEFT <= 2 && (LEFT == 2 ? NTB >= 6 : NTB >= 5);
-  static constexpr int LB0 = (LEFT == 2) ? 4 : (NTB >= 6 ? 5 : 4);
-  static constexpr int LB1 = 5;
-  static constexpr int NPASS = NFULL + ((LEFT > 0 && !SWAPS) ? 1 : 0);   // register passes through LDS
-  static constexpr Lay pass(int p) {
-    if (p < NFULL - 1) return lay_std(L, p * R);
-    if (p == NFULL - 1) return SWAPS ? lay_lane_hi(L, p * R, LEFT, LB0, LB1) : lay_std(L, p * R);
-    return lay_std(L, L - R);                                             // overlapping last pass
+  static constexpr int LW = L < 10 ? L : 10;
+  static constexpr bool HAS_G = L > 10;
+  static constexpr Lay w0() { return lay_std(L, 0); }
+  static constexpr bool W1_WINDOW = (LW > 4 && LW < 8);          // overlapping window, no swaps
+  static constexpr bool HAS_W1 = LW > 4;
+  static constexpr Lay w1() {
+    if (W1_WINDOW) return lay_std(L, L - R);
+    int thr[12] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15};    // t0-3 = bits 0-3, t4 = 8, t5 = 9, waves = 10+
+    return lay_make(L, 4, 5, 6, 7, thr);
   }
-  // first register bit with work in pass p (the overlapping pass only runs the missing top levels)
-  static constexpr int k0(int p) { return p < NFULL ? 0 : R - LEFT; }
-  static constexpr Lay io() { return lay_std(L, L - R); }                 // lanes = low position bits
-  static constexpr Lay swap1() { return lay_swap(pass(NFULL - 1), LB0, 3); }
-  static constexpr Lay swap2() { return lay_swap(swap1(), LB1, 2); }
-  static constexpr Lay final_layout() { return SWAPS ? (LEFT == 2 ? swap2() : swap1()) : pass(NPASS - 1); }
+  static constexpr int W1_K0 = W1_WINDOW ? (R - (LW - 4)) : 0;   // first register bit with work in W1
+  static constexpr int NSWAP = LW >= 8 ? LW - 8 : 0;             // levels reached through lane swaps (0..2)
+  static constexpr Lay w1a() { return lay_swap(w1(), 4, 3); }    // lane bit 4 <-> register bit 3: bit 8
+  static constexpr Lay w1b() { return lay_swap(w1a(), 5, 2); }   // lane bit 5 <-> register bit 2: bit 9
+  static constexpr Lay wave_end() { return NSWAP == 2 ? w1b() : NSWAP == 1 ? w1a() : HAS_W1 ? w1() : w0(); }
+  static constexpr Lay g() { return lay_std(L, L - R); }
+  static constexpr int G_K0 = R - (L - 10);                      // first register bit with work in G
+  // coalesced load/store layout for powerful-basis data that keeps a wave inside its block
+  static constexpr Lay io() {
+    if (L < 10) return lay_std(L, L - R);
+    int thr[12] = {0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15};
+    return lay_make(L, 6, 7, 8, 9, thr);
+  }
+  static constexpr Lay final_layout() { return HAS_G ? g() : wave_end(); }
 };
 
-// forward: data arrives in layout PREV (already in registers)
-template <bool APPROX, int L, int P, Lay PREV>
-__device__ __forceinline__ void fwd_passes(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
-  using S = Sched<L>;
-  if constexpr (P < S::NPASS) {
-    constexpr Lay A = S::pass(P);
-    constexpr int K0 = S::k0(P);
-    const int xt = xthr<A>(tau);
-    transpose_put<PREV, A>(v, lds, tau);
-    LevelTw t0, t1, t2, t3;
-    if constexpr (K0 <= 0) tw_fetch<false, A, 0>(t0, tw, xt);
-    if constexpr (K0 <= 1) tw_fetch<false, A, 1>(t1, tw, xt);
-    if constexpr (K0 <= 2) tw_fetch<false, A, 2>(t2, tw, xt);
-    tw_fetch<false, A, 3>(t3, tw, xt);
-    transpose_get<PREV, A>(v, lds, tau);
-    if constexpr (K0 <= 0) level<APPROX, false, A, 0>(v, t0, tw, qk);
-    if constexpr (K0 <= 1) level<APPROX, false, A, 1>(v, t1, tw, qk);
-    if constexpr (K0 <= 2) level<APPROX, false, A, 2>(v, t2, tw, qk);
-    level<APPROX, false, A, 3>(v, t3, tw, qk);
-    fwd_passes<APPROX, L, P + 1, A>(v, lds, tw, tau, qk);
-  }
+template <bool APPROX, bool INV, Lay A, int K0>
+__device__ __forceinline__ void fetch4(LevelTw (&t)[R], const TwCtx& tw, int xt) {
+  if constexpr (K0 <= 0) tw_fetch<INV, A, 0>(t[0], tw, xt);
+  if constexpr (K0 <= 1) tw_fetch<INV, A, 1>(t[1], tw, xt);
+  if constexpr (K0 <= 2) tw_fetch<INV, A, 2>(t[2], tw, xt);
+  if constexpr (K0 <= 3) tw_fetch<INV, A, 3>(t[3], tw, xt);
 }
-template <bool APPROX, int L, Lay PREV>
-__device__ __forceinline__ void fwd_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
-  using S = Sched<L>;
-  fwd_passes<APPROX, L, 0, PREV>(v, lds, tw, tau, qk);
-  if constexpr (S::SWAPS) {
-    constexpr Lay A1 = S::swap1();
-    LevelTw t;
-    tw_fetch<false, A1, 3>(t, tw, xthr<A1>(tau));
-    lane_swap<S::LB0, 3>(v);
-    level<APPROX, false, A1, 3>(v, t, tw, qk);
-    if constexpr (S::LEFT == 2) {
-      constexpr Lay A2 = S::swap2();
-      LevelTw u;
-      tw_fetch<false, A2, 2>(u, tw, xthr<A2>(tau));
-      lane_swap<S::LB1, 2>(v);
-      level<APPROX, false, A2, 2>(v, u, tw, qk);
-    }
+template <bool APPROX, bool INV, Lay A, int K0>
+__device__ __forceinline__ void levels4(u64 (&v)[E], const LevelTw (&t)[R], const TwCtx& tw, const QK& qk) {
+  if constexpr (!INV) {
+    if constexpr (K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
+    if constexpr (K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
+    if constexpr (K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
+    if constexpr (K0 <= 3) level<APPROX, false, A, 3>(v, t[3], tw, qk);
+  } else {
+    if constexpr (K0 <= 3) level<APPROX, true, A, 3>(v, t[3], tw, qk);
+    if constexpr (K0 <= 2) level<APPROX, true, A, 2>(v, t[2], tw, qk);
+    if constexpr (K0 <= 1) level<APPROX, true, A, 1>(v, t[1], tw, qk);
+    if constexpr (K0 <= 0) level<APPROX, true, A, 0>(v, t[0], tw, qk);
   }
 }
 
-// inverse: data arrives in layout PREV; leaves in layout pass(0)
-template <bool APPROX, int L, int P, Lay PREV>
-__device__ __forceinline__ void inv_passes(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+// forward transform; data arrives in registers in layout PREV, leaves in Sched<L>::final_layout()
+template <bool APPROX, int L, Lay PREV, int SB = 0>
+__device__ __forceinline__ void fwd_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
   using S = Sched<L>;
-  if constexpr (P >= 0) {
-    constexpr Lay A = S::pass(P);
-    constexpr int K0 = S::k0(P);
-    const int xt = xthr<A>(tau);
-    transpose_put<PREV, A>(v, lds, tau);
-    LevelTw t0, t1, t2, t3;
-    tw_fetch<true, A, 3>(t3, tw, xt);
-    if constexpr (K0 <= 2) tw_fetch<true, A, 2>(t2, tw, xt);
-    if constexpr (K0 <= 1) tw_fetch<true, A, 1>(t1, tw, xt);
-    if constexpr (K0 <= 0) tw_fetch<true, A, 0>(t0, tw, xt);
-    transpose_get<PREV, A>(v, lds, tau);
-    level<APPROX, true, A, 3>(v, t3, tw, qk);
-    if constexpr (K0 <= 2) level<APPROX, true, A, 2>(v, t2, tw, qk);
-    if constexpr (K0 <= 1) level<APPROX, true, A, 1>(v, t1, tw, qk);
-    if constexpr (K0 <= 0) level<APPROX, true, A, 0>(v, t0, tw, qk);
-    inv_passes<APPROX, L, P - 1, A>(v, lds, tw, tau, qk);
+  {   // W0: levels 1..4
+    constexpr Lay A = S::w0();
+    LevelTw t[R];
+    // the previous transform's cross-wave reads may still be in flight in other waves
+    if constexpr (S::HAS_G && !lay_eq(PREV, A)) __syncthreads();
+    transpose_put<PREV, A, false>(v, lds, tau);
+    fetch4<APPROX, false, A, 0>(t, tw, xthr<A>(tau));
+    transpose_get<PREV, A, false>(v, lds, tau);
+    LH_STAMP(SB + 2);
+    levels4<APPROX, false, A, 0>(v, t, tw, qk);
+    LH_STAMP(SB + 3);
+  }
+  if constexpr (S::HAS_W1) {   // W1: levels 5..8 (or the window), then lane swaps for 9, 10
+    constexpr Lay A = S::w1();
+    LevelTw t[R];
+    transpose_put<S::w0(), A, false>(v, lds, tau);
+    fetch4<APPROX, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
+    transpose_get<S::w0(), A, false>(v, lds, tau);
+    LH_STAMP(SB + 4);
+    // levels 5..8, with the twiddles of the two lane-swap levels fetched as registers free up
+    if constexpr (S::W1_K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
+    if constexpr (S::W1_K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
+    if constexpr (S::W1_K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
+    LevelTw ua, ub;
+    if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
+    level<APPROX, false, A, 3>(v, t[3], tw, qk);
+    LH_STAMP(SB + 5);
+    if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
+    if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, ua, tw, qk); }
+    if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, ub, tw, qk); }
+    LH_STAMP(SB + 6);
+  }
+  if constexpr (S::HAS_G) {    // the one cross-wave exchange, then levels 11..L
+    constexpr Lay A = S::g();
+    LevelTw t[R];
+    transpose_put<S::wave_end(), A, false>(v, lds, tau);   // writes stay inside the wave's own block
+    fetch4<APPROX, false, A, S::G_K0>(t, tw, xthr<A>(tau));
+    transpose_get<S::wave_end(), A, true>(v, lds, tau);    // barrier, then read across blocks
+    LH_STAMP(SB + 7);
+    levels4<APPROX, false, A, S::G_K0>(v, t, tw, qk);
+    LH_STAMP(SB + 8);
   }
 }
-// data arrives in Sched<L>::final_layout()
-template <bool APPROX, int L>
+
+// inverse transform; data arrives in Sched<L>::final_layout(), leaves in layout NEXT
+template <bool APPROX, int L, Lay NEXT>
 __device__ __forceinline__ void inv_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
   using S = Sched<L>;
-  if constexpr (S::SWAPS) {
-    constexpr Lay A1 = S::swap1();
-    if constexpr (S::LEFT == 2) {
-      constexpr Lay A2 = S::swap2();
-      LevelTw u;
-      tw_fetch<true, A2, 2>(u, tw, xthr<A2>(tau));
-      level<APPROX, true, A2, 2>(v, u, tw, qk);
-      lane_swap<S::LB1, 2>(v);
-    }
-    LevelTw t;
-    tw_fetch<true, A1, 3>(t, tw, xthr<A1>(tau));
-    level<APPROX, true, A1, 3>(v, t, tw, qk);
-    lane_swap<S::LB0, 3>(v);
+  if constexpr (S::HAS_G) {
+    constexpr Lay A = S::g();
+    LevelTw t[R];
+    fetch4<APPROX, true, A, S::G_K0>(t, tw, xthr<A>(tau));
+    levels4<APPROX, true, A, S::G_K0>(v, t, tw, qk);
+    transpose_put<A, S::wave_end(), true>(v, lds, tau);    // barrier (earlier readers), write across blocks
   }
-  inv_passes<APPROX, L, S::NPASS - 1, S::pass(S::NPASS - 1)>(v, lds, tw, tau, qk);
+  if constexpr (S::HAS_W1) {
+    constexpr Lay A = S::w1();
+    const int xt = xthr<A>(tau);
+    LevelTw ua, ub, t[R];
+    if constexpr (S::NSWAP >= 2) tw_fetch<true, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
+    if constexpr (S::NSWAP >= 1) tw_fetch<true, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
+    if constexpr (S::NSWAP == 0) fetch4<APPROX, true, A, S::W1_K0>(t, tw, xt);
+    if constexpr (S::HAS_G) transpose_get<S::g(), S::wave_end(), true>(v, lds, tau);   // barrier, read own block
+    if constexpr (S::NSWAP >= 2) { level<APPROX, true, S::w1b(), 2>(v, ub, tw, qk); lane_swap<5, 2>(v); }
+    if constexpr (S::NSWAP >= 1) {
+      tw_fetch<true, A, 3>(t[3], tw, xt);
+      level<APPROX, true, S::w1a(), 3>(v, ua, tw, qk);
+      lane_swap<4, 3>(v);
+      tw_fetch<true, A, 2>(t[2], tw, xt);
+      tw_fetch<true, A, 1>(t[1], tw, xt);
+      tw_fetch<true, A, 0>(t[0], tw, xt);
+    }
+    levels4<APPROX, true, A, S::W1_K0>(v, t, tw, qk);
+    transpose_put<A, S::w0(), false>(v, lds, tau);
+  }
+  {
+    constexpr Lay A = S::w0();
+    LevelTw t[R];
+    fetch4<APPROX, true, A, 0>(t, tw, xthr<A>(tau));
+    if constexpr (S::HAS_W1) transpose_get<S::w1(), A, false>(v, lds, tau);
+    levels4<APPROX, true, A, 0>(v, t, tw, qk);
+    transpose_put<A, NEXT, false>(v, lds, tau);
+    transpose_get<A, NEXT, false>(v, lds, tau);
+  }
 }
 
 constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
@@ -411,9 +548,10 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);                  // threads per polynomial
   constexpr int PPW = NT >= 256 ? 1 : 256 / NT;     // polynomials per workgroup
-  constexpr int LDSW = n + n / 16;                  // padded words per polynomial
+  constexpr int LDSW = n + n / 16 + twl_words(n);   // padded coefficients + twiddle copy, per polynomial
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* lds = reinterpret_cast<u64*>(smem) + (threadIdx.x / NT) * LDSW;
+  u64* lds_tw = lds + n + n / 16;
   const int tau = threadIdx.x % NT;
 
   // work item -> (b, t); with xcd_map the T components of one polynomial land on
@@ -426,6 +564,11 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
   else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
 
+  if constexpr (PPW == 1) {           // one polynomial per workgroup: make that provable to hipcc
+    t = __builtin_amdgcn_readfirstlane(t);
+    b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
+  }
+  b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
   const ModCtx mc = mod[t];
   const QK qk(mc.q);
   // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
@@ -441,11 +584,17 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * 16u, 0x00020000);
   tw.inv = __builtin_amdgcn_make_buffer_rsrc((void*)tw_inv, 0, (u32)T * n * 16u, 0x00020000);
   tw.comp = (u32)t * (u32)n * 16u;
+  tw.pf = tw_fwd + (size_t)t * n * 2;
+  tw.pi = tw_inv + (size_t)t * n * 2;
+  tw.lds_tw = lds_tw;
+  // levels 5..9 read their twiddles from LDS; (re)filled before the transform direction changes.
+  // Visibility: for L > 10 a workgroup barrier follows before first use; for L <= 10 the
+  // polynomial's own wave does both the fill and the reads.
+  if constexpr (L > 4) tw_fill_lds<NT>(lds_tw, (MODE == 1) ? tw.inv : tw.fwd, tw.comp, n, tau);
   tw.sc0 = scale[(size_t)t * 2];
   tw.sc1 = scale[(size_t)t * 2 + 1];
 
   constexpr Lay LIO = S::io();              // global I/O of powerful-basis data
-  constexpr Lay LP0 = S::pass(0);
   constexpr Lay LFIN = S::final_layout();   // where the forward transform leaves the CRT coefficients
   const u32 uT8 = (u32)T * 8u;
   const u32 pofs = ((u32)(b - b0) * (u32)n * (u32)T + (u32)t) * 8u;       // this polynomial inside the window
@@ -453,11 +602,22 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   const u32 off_fin = pofs + (u32)xthr<LFIN>(tau) * uT8;
 
   u64 v[E];
+  LH_STAMP(0);
+#ifdef LOLHIP_STAMPS
+  if (g_stamp_buf && (threadIdx.x & 63) == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + 30] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
   if constexpr (MODE == 0 || MODE == 2) {
     const rsrc_t src = (MODE == 2) ? ra : ry;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(src, off_io, (u32)xreg(LIO, e) * uT8), qk.q);
+    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk.q);
+    LH_STAMP(1);
     fwd_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+    if constexpr (MODE == 0) LH_STAMP(20);
   }
   if constexpr (MODE == 2) {
     // a-hat does not fit in registers next to b's transform at 4 waves/SIMD, and LDS is
@@ -465,37 +625,49 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     // re-reads exactly the words it wrote, normally still in L2.  The host passes the
     // operand that aliases c (if any) as `a`, so nothing unread is overwritten.
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8, canon_fwd<APPROX>(v[e], qk));
+    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, canon_fwd<APPROX>(v[e], qk));
     __builtin_amdgcn_sched_barrier(0);
+    LH_STAMP(9);
     const bool square = (a_in == b_in);
     if (!square) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(rb, off_io, (u32)xreg(LIO, e) * uT8), qk.q);
-      fwd_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+      for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk.q);
+      LH_STAMP(11);
+      fwd_transform<APPROX, L, LIO, 10>(v, lds, tw, tau, qk);
     }
     __builtin_amdgcn_sched_barrier(0);
+    LH_STAMP(19);
     // a-hat is canonical, b-hat may stay lazy (< 8q): the product is still < q * 2^64
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const u64 ah = load_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8);
+      const u64 ah = load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8);
       const u64 bh = square ? ah : (APPROX ? v[e] : canon_fwd<APPROX>(v[e], qk));
       v[e] = mulmod(ah, bh, mc);
       if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    LH_STAMP(22);
+  }
+  if constexpr (MODE == 2 && L > 4) {
+    // every wave is past its last forward use of the LDS twiddles (the cross-wave barrier of
+    // the final forward stage, or program order inside a wave): switch the copy to the inverse table
+    if constexpr (L > 10) __syncthreads();
+    tw_fill_lds<NT>(lds_tw, tw.inv, tw.comp, n, tau);
   }
   if constexpr (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8), qk.q);
+    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk.q);
   }
   if constexpr (MODE == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)xreg(LFIN, e) * uT8, canon_fwd<APPROX>(v[e], qk));
+    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, canon_fwd<APPROX>(v[e], qk));
+    LH_STAMP(21);
   } else {
-    inv_transform<APPROX, L>(v, lds, tw, tau, qk);
-    transpose_put<LP0, LIO>(v, lds, tau);
-    transpose_get<LP0, LIO>(v, lds, tau);
+    LH_STAMP(23);
+    inv_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+    LH_STAMP(24);
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)xreg(LIO, e) * uT8, canon_inv<APPROX>(v[e], qk));
+    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)lay_tab<LIO>.xr[e] * uT8, canon_inv<APPROX>(v[e], qk));
+    LH_STAMP(25);
   }
 }
 
@@ -504,7 +676,7 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);
   constexpr int PPW = NT >= 256 ? 1 : 256 / NT;
-  constexpr int LDSW = n + n / 16;
+  constexpr int LDSW = n + n / 16 + twl_words(n);
   const size_t lds_bytes = (size_t)PPW * LDSW * sizeof(u64);
   const i64 items = a.B * a.T;
   const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
@@ -539,6 +711,12 @@ static hipError_t launch_pow2_mode(const Pow2Launch& a) {
     default: return hipErrorInvalidValue;
   }
 }
+
+#ifdef LOLHIP_STAMPS
+extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dev, sizeof(dev));
+}
+#endif
 
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (mode) {

@@ -81,10 +81,17 @@ LH_D u64 shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
 // v_mad_u64_u32 (32x32+64 -> 64) and v_lshl_add_u64 are the two 64-bit integer
 // workhorses on gfx950; spelling them out keeps hipcc from splitting the chains into
 // v_mul_lo_u32 + carry adds (each carry add needs a 2-wait-state hazard nop here).
+#ifndef LOLHIP_ASM_MAD
+#define LOLHIP_ASM_MAD 1
+#endif
 LH_D u64 mad64(u32 a, u32 b, u64 c) {
+#if LOLHIP_ASM_MAD
   u64 d, carry;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
   return d;
+#else
+  return (u64)a * (u64)b + c;
+#endif
 }
 LH_D u64 add64(u64 a, u64 b) {
   u64 d;

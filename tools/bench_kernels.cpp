@@ -7,6 +7,7 @@
 #include <vector>
 #include <random>
 #include "../include/lolhip.h"
+#include <dlfcn.h>
 #define CK(x) do{ if((x)!=hipSuccess){ printf("hip error line %d\n", __LINE__); return 1; } }while(0)
 int main(int argc, char** argv){
   int lm = argc>1? atoi(argv[1]) : 14; int T = argc>2? atoi(argv[2]) : 1; long B = argc>3? atol(argv[3]) : 4096;
@@ -21,10 +22,18 @@ int main(int argc, char** argv){
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run=[&]()->int{ if(!strcmp(op,"crt")) return lolhip_crt_batch(P,0,a,B); if(!strcmp(op,"crtinv")) return lolhip_crtinv_batch(P,0,a,B);
     if(!strcmp(op,"roundtrip")){ int r=lolhip_crt_batch(P,0,a,B); return r? r: lolhip_crtinv_batch(P,0,a,B);} return lolhip_polymul_batch(P,0,c,a,b,B); };
+  unsigned long long* dst = nullptr; size_t nw = (size_t)B*T*64; 
+  typedef int (*setfn)(unsigned long long*); setfn sf = (setfn)dlsym(RTLD_DEFAULT, "lolhip_debug_set_stamps");
+  if(sf){ CK(hipMalloc(&dst, nw*32*8)); CK(hipMemset(dst,0,nw*32*8)); sf(dst); }
   for(int i=0;i<2;i++) if((rc=run())){ printf("run rc=%d\n",rc); return 1; }
   CK(hipDeviceSynchronize()); CK(hipEventRecord(e0,0)); for(int i=0;i<iters;i++) run(); CK(hipEventRecord(e1,0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
   double bytes = (!strcmp(op,"polymul")?3.0:(!strcmp(op,"roundtrip")?4.0:2.0))*cnt*8;
+  if(sf){ run(); CK(hipDeviceSynchronize()); int wpb = (n/16>=256? n/16:256)/64; size_t nwv=(size_t)((B*T*(n/16>=256?1:1)))*wpb; std::vector<unsigned long long> hs(nwv*32);
+    CK(hipMemcpy(hs.data(),dst,nwv*32*8,hipMemcpyDeviceToHost)); double sum[32]={0}; long cnt[32]={0}; int last=-1; 
+    for(size_t w=0;w<nwv;w++){ int prev=-1; for(int i=0;i<32;i++){ if(hs[w*32+i]==0) continue; if(prev>=0){ sum[i]+= (double)(hs[w*32+i]-hs[w*32+prev]); cnt[i]++; } prev=i; } }
+    if(getenv("LOLHIP_STAMP_DUMP")){ FILE* f=fopen(getenv("LOLHIP_STAMP_DUMP"),"wb"); fwrite(hs.data(),8,hs.size(),f); fclose(f); }
+    for(int i=0;i<32;i++) if(cnt[i]) printf("  stamp %2d: +%8.0f cycles (avg over %ld waves)\n", i, sum[i]/cnt[i], cnt[i]); (void)last; }
   printf("%s m=2^%d n=%ld T=%d B=%ld q~2^%d: %.4f ms/iter  %.3f M items/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", op, lm, n, T, B, qbits, ms, B/ms/1e3, bytes/ms/1e6, bytes/ms/1e6/80.0);
   return 0;
 }
