@@ -61,6 +61,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels carry their own libamdhip64; if torch is going to be used in this
+    # process it must be the one that loads the HIP runtime first, or its later device probe
+    # finds the GPU already claimed by a second runtime copy ("No HIP GPUs are available").
+    if os.environ.get("LOLHIP_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,503 @@
+"""GPU parity tests (-m gpu): every entry point of include/lolhip.h, called through the C ABI,
+against (a) the committed golden vectors produced by the reference's own C++, (b) the CPU
+oracle on fresh seeded inputs, and (c) at BASELINE.json's full sizes, size-independent
+properties plus strided samples.  Bit-exact everywhere (integer arithmetic).
+
+All comparisons are `np.array_equal`; there is no tolerance in this file.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import lolmath as lm
+from oracle.oracle import Params
+from params import BIG, PLAN_NAME, PRIME_OPS, PRIMEOPS_ONLY, TENSOR1, TENSOR2, BENCH1, BENCH2
+
+pytestmark = pytest.mark.gpu
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a).astype(np.int64))
+
+
+def _params_nocrt(m, qs):
+    P = Params.__new__(Params)
+    P.pps = lm.factor_pps(m)
+    P.qs, P.T, P.m, P.n = list(qs), len(qs), m, lm.totient_pps(P.pps)
+    return P
+
+
+# ---------------------------------------------------------------------------------------
+# (a) golden vectors from the reference's own lol-cpp (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("i", range(len(TENSOR1)))
+def test_golden_tensor1(gpu, golden, i):
+    m, qs = TENSOR1[i]
+    P = gpu.Plan(lm.factor_pps(m), qs)
+    y, z = _i64(golden[f"t1_{i}/y"]), _i64(golden[f"t1_{i}/z"])
+    assert np.array_equal(P.crt(y), _i64(golden[f"t1_{i}/crt"]))
+    assert np.array_equal(P.crtInv(y), _i64(golden[f"t1_{i}/crtinv"]))
+    assert np.array_equal(P.mul(y, z), _i64(golden[f"t1_{i}/mul"]))
+    assert np.array_equal(P.polymul(y, z), _i64(golden[f"t1_{i}/polymul"]))
+    for op in PRIME_OPS:
+        got = getattr(P, PLAN_NAME[op])(y)
+        key = f"t1_{i}/{op}"
+        if key in golden:
+            assert np.array_equal(got, _i64(golden[key])), op
+        else:
+            assert got is None, op
+
+
+@pytest.mark.parametrize("i", range(len(PRIMEOPS_ONLY)))
+def test_golden_noncrt_moduli(gpu, golden, i):
+    m, qs = PRIMEOPS_ONLY[i]
+    P = gpu.Plan(lm.factor_pps(m), qs)
+    assert not P.has_crt
+    y = _i64(golden[f"po_{i}/y"])
+    for op in PRIME_OPS:
+        got = getattr(P, PLAN_NAME[op])(y)
+        key = f"po_{i}/{op}"
+        if key in golden:
+            assert np.array_equal(got, _i64(golden[key])), op
+        else:
+            assert got is None
+    with pytest.raises(gpu.LolHipError):
+        P.crt(y)
+
+
+@pytest.mark.parametrize("i", range(len(BIG)))
+def test_golden_baseline_configs(gpu, golden, i):
+    """config 1 exactly (m=1024, q=12289, seed 1) and configs 2/4 at CT-valid moduli."""
+    m, qs, _seed = BIG[i]
+    P = gpu.Plan(lm.factor_pps(m), qs)
+    y, z = _i64(golden[f"big_{i}/y"]), _i64(golden[f"big_{i}/z"])
+    assert np.array_equal(P.crt(y), _i64(golden[f"big_{i}/crt"]))
+    assert np.array_equal(P.crtInv(y), _i64(golden[f"big_{i}/crtinv"]))
+    assert np.array_equal(P.polymul(y, z), _i64(golden[f"big_{i}/polymul"]))
+
+
+@pytest.mark.parametrize("i", range(len(TENSOR2)))
+def test_golden_twace_embed(gpu, golden, i):
+    m, m2, qs = TENSOR2[i]
+    X = gpu.Ext(gpu.Plan(lm.factor_pps(m), qs), gpu.Plan(lm.factor_pps(m2), qs))
+    lo, hi = _i64(golden[f"t2_{i}/lo"]), _i64(golden[f"t2_{i}/hi"])
+    assert np.array_equal(X.embedPow(lo), _i64(golden[f"t2_{i}/embed_pow"]))
+    assert np.array_equal(X.twacePowDec(hi), _i64(golden[f"t2_{i}/twace_powdec"]))
+    assert np.array_equal(X.embedCRT(lo), _i64(golden[f"t2_{i}/embed_crt"]))
+    assert np.array_equal(X.twaceCRT(hi), _i64(golden[f"t2_{i}/twace_crt"]))
+    assert np.array_equal(X.embedDec(lo), _i64(golden[f"t2_{i}/embed_dec"]))
+
+
+# ---------------------------------------------------------------------------------------
+# the ten drop-in symbols, called exactly as lol-cpp's Haskell shim calls them
+# (Backend.hs:193-241): host pointers, in place, caller-supplied twiddles
+# ---------------------------------------------------------------------------------------
+
+class _PP(C.Structure):
+    _fields_ = [("prime", C.c_int16), ("exponent", C.c_int16)]
+
+
+def _dropin(gpu):
+    L = C.CDLL(gpu.lib_path())
+    i16, i64, vp = C.c_int16, C.c_int64, C.c_void_p
+    L.tensorCRTRq.argtypes = [i16, vp, i64, vp, i16, vp, vp]
+    L.tensorCRTInvRq.argtypes = [i16, vp, i64, vp, i16, vp, vp, vp]
+    L.mulRq.argtypes = [i16, vp, vp, i64, vp]
+    for nm in ("tensorLRq", "tensorLInvRq", "tensorGPowRq", "tensorGDecRq", "tensorGInvPowRq", "tensorGInvDecRq"):
+        getattr(L, nm).argtypes = [i16, vp, i64, vp, i16, vp]
+    for nm in ("tensorCRTRq", "tensorCRTInvRq", "mulRq", "tensorLRq", "tensorLInvRq", "tensorGPowRq", "tensorGDecRq"):
+        getattr(L, nm).restype = None
+    L.tensorGInvPowRq.restype = i16
+    L.tensorGInvDecRq.restype = i16
+    return L
+
+
+@pytest.mark.parametrize("m,qs", TENSOR1 + [(1024, [12289]), (45, [1171, 1531]), (2 ** 14, [lm.first_good_q(2 ** 14, 2 ** 60)])])
+def test_dropin_symbols(gpu, cpuref, m, qs):
+    L = _dropin(gpu)
+    P = Params(lm.factor_pps(m), qs)
+    rng = np.random.default_rng(m + 5)
+    pe = (_PP * max(1, len(P.pps)))()
+    for k, (p, e) in enumerate(P.pps):
+        pe[k].prime, pe[k].exponent = p, e
+    q = np.array(qs, dtype=np.int64)
+    ru = [np.array(t, dtype=np.int64) for t in P.ru]
+    rui = [np.array(t, dtype=np.int64) for t in P.ruinv]
+    rup = (C.c_void_p * max(1, len(ru)))(*[a.ctypes.data for a in ru])
+    ruip = (C.c_void_p * max(1, len(rui)))(*[a.ctypes.data for a in rui])
+    mh = np.array(P.mhatinv, dtype=np.int64)
+    y0 = P.random(rng, 1)[0]
+    y = y0.copy()
+    L.tensorCRTRq(P.T, y.ctypes.data, P.n, pe, len(P.pps), rup, q.ctypes.data)
+    assert L.lolhip_last_status() == 0
+    assert np.array_equal(y, cpuref.crt(P, y0).reshape(y0.shape))
+    L.tensorCRTInvRq(P.T, y.ctypes.data, P.n, pe, len(P.pps), ruip, mh.ctypes.data, q.ctypes.data)
+    assert np.array_equal(y, y0)
+    z = P.random(rng, 1)[0]
+    a = y0.copy()
+    L.mulRq(P.T, a.ctypes.data, z.ctypes.data, P.n, q.ctypes.data)
+    assert np.array_equal(a, cpuref.mul(P, y0, z).reshape(y0.shape))
+    for sym, op in (("tensorLRq", "l"), ("tensorLInvRq", "linv"), ("tensorGPowRq", "gpow"), ("tensorGDecRq", "gdec")):
+        a = y0.copy()
+        getattr(L, sym)(P.T, a.ctypes.data, P.n, pe, len(P.pps), q.ctypes.data)
+        assert np.array_equal(a, getattr(cpuref, op)(P, y0).reshape(y0.shape)), sym
+    for sym, op in (("tensorGInvPowRq", "ginvpow"), ("tensorGInvDecRq", "ginvdec")):
+        a = y0.copy()
+        ret = getattr(L, sym)(P.T, a.ctypes.data, P.n, pe, len(P.pps), q.ctypes.data)
+        want = getattr(cpuref, op)(P, y0)
+        assert (ret == 1) == (want is not None)
+        if want is not None:
+            assert np.array_equal(a, want.reshape(y0.shape)), sym
+
+
+def test_dropin_honours_caller_roots(gpu, cpuref):
+    """The reference transforms with whatever roots the caller marshals (CPP.hs:422-432);
+    a different primitive root must give the matching different CRT."""
+    m, q = 32, 97
+    pps = lm.factor_pps(m)
+    P = Params(pps, [q])
+    w = lm.omega(m, q)
+    w2 = pow(w, 3, q)                       # another primitive 32nd root
+    P.ru = [[pow(w2, i, q) for i in range(m)]]
+    rng = np.random.default_rng(0)
+    y0 = P.random(rng, 1)[0]
+    L = _dropin(gpu)
+    pe = (_PP * 1)()
+    pe[0].prime, pe[0].exponent = 2, 5
+    ru = np.array(P.ru[0], dtype=np.int64)
+    rup = (C.c_void_p * 1)(ru.ctypes.data)
+    qa = np.array([q], dtype=np.int64)
+    y = y0.copy()
+    L.tensorCRTRq(1, y.ctypes.data, P.n, pe, 1, rup, qa.ctypes.data)
+    assert np.array_equal(y, cpuref.crt(P, y0).reshape(y0.shape))
+    assert not np.array_equal(y, cpuref.crt(Params(pps, [q]), y0).reshape(y0.shape))
+
+
+# ---------------------------------------------------------------------------------------
+# (b) fresh random inputs against the oracle: every n = 2^L the fast path instantiates,
+#     31/61-bit moduli, RNS tuples, mixed-radix indices, batch shapes
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("L", range(1, 15))
+@pytest.mark.parametrize("T,lower", [(1, 2 ** 60), (3, 2 ** 29), (2, 2 ** 61)])
+def test_pow2_all_sizes(gpu, cpuref, L, T, lower):
+    m = 2 ** (L + 1)
+    g = lm.good_qs(m, lower)
+    qs = [next(g) for _ in range(T)]
+    P, R = gpu.Plan([(2, L + 1)], qs), Params([(2, L + 1)], qs)
+    rng = np.random.default_rng(L * 10 + T)
+    for B in (1, 5):
+        y, z = R.random(rng, B), R.random(rng, B)
+        assert np.array_equal(P.crt(y), cpuref.crt(R, y))
+        assert np.array_equal(P.crtInv(y), cpuref.crtinv(R, y))
+        assert np.array_equal(P.polymul(y, z), cpuref.polymul(R, y, z))
+        assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y))       # squaring path (a is b)
+
+
+@pytest.mark.parametrize("m", [3, 5, 9, 15, 21, 25, 27, 33, 36, 45, 49, 63, 89, 105, 121, 280, 432, 1155, 1728, 5184, 14400, 15015])
+def test_generic_indices(gpu, cpuref, m):
+    pps = lm.factor_pps(m)
+    for T, lower in ((1, 2 ** 60), (2, 2 ** 30)):
+        g = lm.good_qs(m, lower)
+        qs = [next(g) for _ in range(T)]
+        P, R = gpu.Plan(pps, qs), Params(pps, qs)
+        rng = np.random.default_rng(m)
+        B = 3 if R.n <= 2000 else 1
+        y, z = R.random(rng, B), R.random(rng, B)
+        for op in ("crt", "crtinv") + PRIME_OPS:
+            got, want = getattr(P, PLAN_NAME[op])(y), getattr(cpuref, op)(R, y)
+            assert (got is None) == (want is None), op
+            if want is not None:
+                assert np.array_equal(got, want), (op, m, qs)
+        assert np.array_equal(P.mul(y, z), cpuref.mul(R, y, z))
+        assert np.array_equal(P.polymul(y, z), cpuref.polymul(R, y, z))
+        # mulGCRT = crt . mulGPow . crtInv ; divGCRT its inverse (TensorTests.hs:107-112)
+        assert np.array_equal(P.mulGCRT(y), cpuref.crt(R, cpuref.gpow(R, cpuref.crtinv(R, y))))
+        assert np.array_equal(P.divGCRT(P.mulGCRT(y)), y)
+
+
+@pytest.mark.parametrize("m,q", BENCH1)
+def test_reference_benchmark_parameters(gpu, cpuref, m, q):
+    """lol/Crypto/Lol/Benchmarks/Default.hs:42-46"""
+    pps = lm.factor_pps(m)
+    P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+    y = R.random(np.random.default_rng(q), 4)
+    assert np.array_equal(P.crt(y), cpuref.crt(R, y))
+    assert np.array_equal(P.crtInv(P.crt(y)), y)
+    assert np.array_equal(P.lInv(P.l(y)), y)
+    assert np.array_equal(P.divGPow(P.mulGPow(y)), y)
+    assert np.array_equal(P.divGDec(P.mulGDec(y)), y)
+
+
+@pytest.mark.parametrize("m,m2,q", BENCH2 + [(12, 60, 61), (9, 45, 181), (1, 8, 17), (8, 8, 17), (56, 2912, 8737)])
+def test_twace_embed_vs_oracle(gpu, cpuref, m, m2, q):
+    a, b = lm.factor_pps(m), lm.factor_pps(m2)
+    qs = [q, lm.first_good_q(m2, q)]
+    Pl, Ph = gpu.Plan(a, qs), gpu.Plan(b, qs)
+    X = gpu.Ext(Pl, Ph)
+    Rl, Rh = Params(a, qs), Params(b, qs)
+    rng = np.random.default_rng(m2)
+    lo, hi = Rl.random(rng, 2), Rh.random(rng, 2)
+    assert np.array_equal(X.embedPow(lo), cpuref.embed_pow(Rl, Rh, lo))
+    assert np.array_equal(X.embedDec(lo), cpuref.embed_dec(Rl, Rh, lo))
+    assert np.array_equal(X.embedCRT(lo), cpuref.embed_crt(Rl, Rh, lo))
+    assert np.array_equal(X.twacePowDec(hi), cpuref.twace_powdec(Rl, Rh, hi))
+    assert np.array_equal(X.twaceCRT(hi), cpuref.twace_crt(Rl, Rh, hi))
+    # the reference's identities (TensorTests.hs:133-234), with the GPU on both sides
+    assert np.array_equal(X.twacePowDec(X.embedPow(lo)), lo)
+    assert np.array_equal(X.twaceCRT(X.embedCRT(lo)), lo)
+    assert np.array_equal(X.embedCRT(lo), Ph.crt(X.embedPow(Pl.crtInv(lo))))
+    assert np.array_equal(X.twaceCRT(hi), Pl.crt(X.twacePowDec(Ph.crtInv(hi))))
+    assert np.array_equal(X.embedDec(lo), Ph.lInv(X.embedPow(Pl.l(lo))))
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------
+
+def test_empty_and_ragged_batches(gpu, cpuref):
+    for m in (64, 512, 45):           # packed pow2 launch (several polynomials per workgroup), generic
+        pps = lm.factor_pps(m)
+        q = lm.first_good_q(m, 2 ** 40)
+        P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+        empty = np.zeros((0, R.n, 1), dtype=np.int64)
+        assert P.crt(empty).shape == (0, R.n, 1)
+        assert P.polymul(empty, empty).shape == (0, R.n, 1)
+        rng = np.random.default_rng(m)
+        for B in (1, 2, 3, 7, 13, 33):
+            y, z = R.random(rng, B), R.random(rng, B)
+            assert np.array_equal(P.crt(y), cpuref.crt(R, y)), (m, B)
+            assert np.array_equal(P.crtInv(y), cpuref.crtinv(R, y)), (m, B)
+            assert np.array_equal(P.polymul(y, z), cpuref.polymul(R, y, z)), (m, B)
+
+
+def test_negative_representatives(gpu, cpuref):
+    """inputs in (-q, q) as the reference's Zq allows (types.h:52-57); outputs canonical"""
+    for m in (21, 256, 2 ** 12):
+        pps = lm.factor_pps(m)
+        q = lm.first_good_q(m, 2 ** 45)
+        P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+        y = R.random(np.random.default_rng(1), 2) - q // 2
+        z = R.random(np.random.default_rng(2), 2) - q // 3
+        for op in ("crt", "crtinv") + PRIME_OPS:
+            got = getattr(P, PLAN_NAME[op])(y)
+            assert np.array_equal(got, getattr(cpuref, op)(R, y)), op
+            assert got.min() >= 0 and got.max() < q
+        assert np.array_equal(P.mul(y, z), cpuref.mul(R, y, z))
+        assert np.array_equal(P.polymul(y, z), cpuref.polymul(R, y, z))
+
+
+def test_extreme_values_and_moduli(gpu, cpuref):
+    """all-zero, all-(q-1), and moduli at both ends of the supported range"""
+    for m, lower in ((2 ** 10, 2 ** 62 - 2 ** 30), (2 ** 10, 2 ** 61 - 2 ** 20), (2 ** 10, 2 ** 61 + 5), (16, 16), (45, 2 ** 61)):
+        pps = lm.factor_pps(m)
+        q = lm.first_good_q(m, lower)
+        if q >= 2 ** 62:
+            continue
+        P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+        for fill in (0, q - 1, 1):
+            y = np.full((2, R.n, 1), fill, dtype=np.int64)
+            assert np.array_equal(P.crt(y), cpuref.crt(R, y))
+            assert np.array_equal(P.crtInv(y), cpuref.crtinv(R, y))
+            assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y))
+    with pytest.raises(gpu.LolHipError):
+        gpu.Plan([(2, 4)], [2 ** 62 + 1])
+
+
+def test_divg_failure_is_reported(gpu):
+    """oddRad(m) not invertible mod q -> Nothing in the reference (g.cpp:194-199, CPP.hs:321-323)"""
+    P = gpu.Plan([(3, 1), (7, 1)], [21])
+    y = np.arange(12, dtype=np.int64).reshape(1, 12, 1)
+    assert P.divGPow(y) is None and P.divGDec(y) is None
+    assert P.mulGPow(y) is not None
+
+
+def test_large_generic_polynomial_uses_scratch_path(gpu, cpuref):
+    """n = 16384 with a non power-of-two index: stage program runs out of HBM scratch"""
+    m = 3 * 2 ** 14
+    pps = lm.factor_pps(m)
+    q = lm.first_good_q(m, 2 ** 50)
+    P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+    assert R.n == 16384
+    y = R.random(np.random.default_rng(4), 2)
+    assert np.array_equal(P.crt(y), cpuref.crt(R, y))
+    assert np.array_equal(P.crtInv(y), cpuref.crtinv(R, y))
+    assert np.array_equal(P.l(y), cpuref.l(R, y))
+    assert np.array_equal(P.divGDec(y), cpuref.ginvdec(R, y))
+
+
+# ---------------------------------------------------------------------------------------
+# device-pointer API (what bench.py times) + aliasing rules of polymul
+# ---------------------------------------------------------------------------------------
+
+def test_device_tensors_and_aliasing(gpu, cpuref):
+    torch = pytest.importorskip("torch")
+    for m in (2 ** 12, 2 ** 14, 45):
+        pps = lm.factor_pps(m)
+        g = lm.good_qs(m, 2 ** 58)
+        qs = [next(g), next(g)]
+        P, R = gpu.Plan(pps, qs), Params(pps, qs)
+        rng = np.random.default_rng(m)
+        a, b = R.random(rng, 6), R.random(rng, 6)
+        want = cpuref.polymul(R, a, b)
+        da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        dc = torch.empty_like(da)
+        P.polymul(da, db, out=dc)
+        assert np.array_equal(dc.cpu().numpy(), want)
+        assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b)   # inputs untouched
+        x = da.clone(); P.polymul(x, db, out=x)                                            # c aliases a
+        assert np.array_equal(x.cpu().numpy(), want)
+        x = db.clone(); P.polymul(da, x, out=x)                                            # c aliases b
+        assert np.array_equal(x.cpu().numpy(), want)
+        x = da.clone(); P.polymul(x, x, out=x)                                             # in-place square
+        assert np.array_equal(x.cpu().numpy(), cpuref.polymul(R, a, a))
+        x = da.clone(); P.crt(x); P.crtInv(x)
+        assert np.array_equal(x.cpu().numpy(), a)
+        x = da.clone(); P.mulGPow(x); P.divGPow(x)
+        assert np.array_equal(x.cpu().numpy(), a)
+        x = da.clone(); P.mul(x, db)
+        assert np.array_equal(x.cpu().numpy(), cpuref.mul(R, a, b))
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            x = da.clone(); P.crt(x, stream=s.cuda_stream); s.synchronize()
+        assert np.array_equal(x.cpu().numpy(), cpuref.crt(R, a))
+
+
+# ---------------------------------------------------------------------------------------
+# (c) BASELINE.json full sizes: properties on the whole batch + strided samples vs the oracle
+# ---------------------------------------------------------------------------------------
+
+def _sample(cpuref_fn, got, B, k=3):
+    idx = sorted(set([0, B // 2, B - 1]))[:k]
+    return idx
+
+
+def test_config2_full_batch(gpu, cpuref):
+    """m = 2^14, 61-bit q, batch 4096: crtInv.crt = id over the batch; poly-mul samples and
+    ring identities (commutativity, distributivity, multiplication by the constant 1)."""
+    torch = pytest.importorskip("torch")
+    m = 2 ** 14
+    q = lm.first_good_q(m, 2 ** 60)
+    P, R = gpu.Plan([(2, 14)], [q]), Params([(2, 14)], [q])
+    B, n = 4096, R.n
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    a = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
+    b = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
+    x = a.clone(); P.crt(x); P.crtInv(x)
+    assert torch.equal(x, a)
+    c = torch.empty_like(a); P.polymul(a, b, out=c)
+    c2 = torch.empty_like(a); P.polymul(b, a, out=c2)
+    assert torch.equal(c, c2)                                              # commutative
+    idx = [0, 1, B // 3, B - 1]
+    want = cpuref.polymul(R, a[idx].cpu().numpy(), b[idx].cpu().numpy())
+    assert np.array_equal(c[idx].cpu().numpy(), want)
+    # (a + b) * b == a*b + b*b  (distributive), all mod q
+    s = (a + b) % q
+    l1 = torch.empty_like(a); P.polymul(s, b, out=l1)
+    bb = torch.empty_like(a); P.polymul(b, b, out=bb)
+    assert torch.equal(l1, (c + bb) % q)
+    one = torch.zeros_like(a); one[:, 0, :] = 1                              # scalarPow 1 (CPP.hs:413-417)
+    u = torch.empty_like(a); P.polymul(a, one, out=u)
+    assert torch.equal(u, a)
+    # checksum of checksums against the sampled oracle rows is covered above; sortedness n/a
+
+
+def test_config3_she_ciphertext_product(gpu, cpuref):
+    """m = 2^15, four ~59-bit moduli: (c0,c1)*(d0,d1) -> mulG of the three products
+    (SymmSHE.hs:444-452), all on the GPU, sample rows against the oracle composition."""
+    torch = pytest.importorskip("torch")
+    m = 2 ** 15
+    g = lm.good_qs(m, 2 ** 59)
+    qs = [next(g) for _ in range(4)]
+    P, R = gpu.Plan([(2, 15)], qs), Params([(2, 15)], qs)
+    B = 64
+    rng = np.random.default_rng(3)
+    c0, c1, d0, d1 = (R.random(rng, B) for _ in range(4))
+    t = {k: torch.from_numpy(v).cuda() for k, v in dict(c0=c0, c1=c1, d0=d0, d1=d1).items()}
+    qv = torch.tensor(qs, dtype=torch.int64, device="cuda")
+    e0 = torch.empty_like(t["c0"]); P.polymul(t["c0"], t["d0"], out=e0)
+    x01 = torch.empty_like(e0); P.polymul(t["c0"], t["d1"], out=x01)
+    x10 = torch.empty_like(e0); P.polymul(t["c1"], t["d0"], out=x10)
+    e1 = (x01 + x10) % qv
+    e2 = torch.empty_like(e0); P.polymul(t["c1"], t["d1"], out=e2)
+    for e in (e0, e1, e2):
+        P.mulGPow(e)                       # identity for m = 2^k apart from canonicalisation
+    idx = [0, B - 1]
+    w0 = cpuref.gpow(R, cpuref.polymul(R, c0[idx], d0[idx]))
+    w2 = cpuref.gpow(R, cpuref.polymul(R, c1[idx], d1[idx]))
+    s = (cpuref.polymul(R, c0[idx], d1[idx]).astype(object) + cpuref.polymul(R, c1[idx], d0[idx]).astype(object)) % np.array(qs, dtype=object)
+    assert np.array_equal(e0[idx].cpu().numpy(), w0)
+    assert np.array_equal(e2[idx].cpu().numpy(), w2)
+    assert np.array_equal(e1[idx].cpu().numpy(), cpuref.gpow(R, s.astype(np.int64)))
+
+
+def test_config4_mixed_radix_full_batch(gpu, cpuref):
+    """m = 15015 = 3*5*7*11*13 (n = 5760), batch 1024, q just above 2^60 and 2^30"""
+    torch = pytest.importorskip("torch")
+    m = 15015
+    pps = lm.factor_pps(m)
+    for lower in (2 ** 60, 2 ** 30):
+        q = lm.first_good_q(m, lower)
+        P, R = gpu.Plan(pps, [q]), Params(pps, [q])
+        B = 1024
+        g = torch.Generator(device="cuda"); g.manual_seed(4)
+        a = torch.randint(0, q, (B, R.n, 1), dtype=torch.int64, device="cuda", generator=g)
+        x = a.clone(); P.crt(x)
+        idx = [0, 511, 1023]
+        assert np.array_equal(x[idx].cpu().numpy(), cpuref.crt(R, a[idx].cpu().numpy()))
+        P.crtInv(x)
+        assert torch.equal(x, a)
+        x = a.clone(); P.mulGDec(x); P.divGDec(x)
+        assert torch.equal(x, a)
+        x = a.clone(); P.l(x); P.lInv(x)
+        assert torch.equal(x, a)
+
+
+def test_config5_keyswitch_shapes(gpu, cpuref):
+    """n = 1024, two 20-bit moduli (lol-apps Benchmarks/Default.hs:49), a large batch:
+    the op mix of a TrivGad key switch — crtInv, per-component lift, crt, multiply-accumulate
+    with the hint — plus ring embed 2048 -> 2048*7 (SymmSHE.hs:302-314, 361-371, 477-487)."""
+    torch = pytest.importorskip("torch")
+    m, m2 = 2048, 2048 * 7
+    qs = [1017857, 1032193]
+    qs_ok = all(lm.is_prime(q) and (q - 1) % m == 0 for q in qs)
+    assert qs_ok
+    P, R = gpu.Plan([(2, 11)], qs), Params([(2, 11)], qs)
+    B = 8192
+    rng = np.random.default_rng(5)
+    c2 = R.random(rng, B)                       # the quadratic ciphertext component, CRT basis
+    hint0, hint1 = R.random(rng, 1), R.random(rng, 1)
+    d = torch.from_numpy(c2).cuda()
+    P.crtInv(d)                                 # decompose works in the powerful basis
+    digits = []
+    for t, qt in enumerate(qs):                 # TrivGad: digit t = lift of component t, reduced mod every q
+        lifted = d[:, :, t:t + 1].clone()
+        half = qt // 2
+        lifted = torch.where(lifted > half, lifted - qt, lifted)      # centred lift (ZqBasic.hs:227-232)
+        dig = torch.remainder(lifted.expand(-1, -1, len(qs)), torch.tensor(qs, device="cuda")).contiguous()
+        P.crt(dig)
+        digits.append(dig)
+    h0 = torch.from_numpy(np.broadcast_to(hint0, c2.shape).copy()).cuda()
+    acc = torch.zeros_like(d)
+    for dig in digits:
+        prod = dig.clone(); P.mul(prod, h0)
+        acc = (acc + prod) % torch.tensor(qs, device="cuda")
+    # oracle for two sample rows
+    idx = [0, B - 1]
+    pw = cpuref.crtinv(R, c2[idx])
+    want = np.zeros_like(pw)
+    for t, qt in enumerate(qs):
+        lifted = pw[:, :, t:t + 1].astype(np.int64)
+        lifted = np.where(lifted > qt // 2, lifted - qt, lifted)
+        dig = np.mod(np.broadcast_to(lifted, pw.shape), np.array(qs)).astype(np.int64)
+        want = (want + cpuref.mul(R, cpuref.crt(R, dig), np.broadcast_to(hint0, dig.shape))) % np.array(qs)
+    assert np.array_equal(acc[idx].cpu().numpy(), want)
+    # ring embed of the result into the larger ring, CRT basis both sides
+    g2 = [q for q in qs if (q - 1) % m2 == 0]
+    if len(g2) == len(qs):
+        Ph = gpu.Plan(lm.factor_pps(m2), qs)
+        X = gpu.Ext(P, Ph)
+        e = X.embedCRT(acc[:16].contiguous())
+        assert np.array_equal(X.twaceCRT(e).cpu().numpy(), acc[:16].cpu().numpy())
