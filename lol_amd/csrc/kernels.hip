@@ -216,12 +216,18 @@ __device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u64&
   wp = ((u64)r.w << 32) | r.z;
 }
 __device__ __forceinline__ u64 load_u64(rsrc_t r, u32 voff, u32 soff) {
+#ifdef LOLHIP_ABL_NO_IO       // ablation: compute-only timing, results are garbage
+  return (u64)voff * 0x9E3779B97F4A7C15ull + soff;
+#endif
   const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return ((u64)x.y << 32) | x.x;
 }
 __device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val) {
   u32x2 x;
   x.x = (u32)val; x.y = (u32)(val >> 32);
+#ifdef LOLHIP_ABL_NO_IO
+  if (val != 0x1234567ull) return;
+#endif
   __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 

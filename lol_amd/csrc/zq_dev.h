@@ -82,10 +82,14 @@ LH_D u64 shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
 // workhorses on gfx950; spelling them out keeps hipcc from splitting the chains into
 // v_mul_lo_u32 + carry adds (each carry add needs a 2-wait-state hazard nop here).
 #ifndef LOLHIP_ASM_MAD
-#define LOLHIP_ASM_MAD 1
+#define LOLHIP_ASM_MAD 3
 #endif
 LH_D u64 mad64(u32 a, u32 b, u64 c) {
-#if LOLHIP_ASM_MAD
+#if LOLHIP_ASM_MAD == 2
+  u64 d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return d;
+#elif LOLHIP_ASM_MAD
   u64 d, carry;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
   return d;
@@ -118,6 +122,33 @@ LH_D u64 csubn(u64 x, u64 negm) {
 // so (result - init) = w*y mod q + {0..3}*q  in [0, 4q) for any 64-bit y.  7 mads + 2
 // mul_hi instead of the 10 multiplies of the exact form; nq = -q (mod 2^64).
 LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
+#if LOLHIP_ASM_MAD == 3
+  // Two asm blocks per product (hipcc pads every separate asm statement that writes an SGPR
+  // carry with s_nop; inside a block there is nothing to pad: VGPR RAW is interlocked).
+  u64 Q, t, h;
+  u32 ah, bh;
+  asm("v_mul_hi_u32 %1, %3, %5\n\t"
+      "v_mul_hi_u32 %2, %4, %6\n\t"
+      "v_mad_u64_u32 %0, vcc, %3, %6, 0\n\t"
+      "v_mad_u64_u32 %0, vcc, %1, 1, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %2, 1, %0"
+      : "=&v"(Q), "=&v"(ah), "=&v"(bh)
+      : "v"(hi32(wp)), "v"(lo32(wp)), "v"(lo32(y)), "v"(hi32(y))
+      : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %2, %4, %10\n\t"
+      "v_mad_u64_u32 %1, vcc, %2, %5, 0\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
+      "v_mad_u64_u32 %1, vcc, %3, %4, %1\n\t"
+      "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
+      "v_mad_u64_u32 %1, vcc, %7, %8, %1"
+      : "=&v"(t), "=&v"(h)
+      : "v"(lo32(w)), "v"(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),
+        "v"(lo32(nq)), "v"(hi32(nq)), "v"(init)
+      : "vcc");
+  u32 th;
+  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  return ((u64)th << 32) | lo32(t);
+#else
   const u32 ah = __umulhi(hi32(wp), lo32(y));
   const u32 bh = __umulhi(lo32(wp), hi32(y));
   const u64 Q = mad64(bh, 1u, mad64(hi32(wp), hi32(y), (u64)ah));
@@ -130,6 +161,7 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
   u32 th;
   asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
   return ((u64)th << 32) | lo32(t);
+#endif
 }
 
 // remainder of the 128-bit value (u1:u0) by c.q, requires (u1:u0) < q * 2^64
