@@ -165,8 +165,7 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   if (B < 0 || (B > 0 && (!a || !b || !c))) return LOLHIP_ERR_INVALID;
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
-  // the kernel parks crt(a) in c before it reads b: hand it the operand that aliases c first
-  if (P.is_pow2) return (c == b) ? run_pow2(P, 2, s, c, b, a, B) : run_pow2(P, 2, s, c, a, b, B);
+  if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
   // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.
   const size_t bytes = sizeof(int64_t) * (size_t)(B * P.n * P.T);
   if (bytes == 0) return LOLHIP_OK;

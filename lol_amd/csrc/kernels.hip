@@ -239,7 +239,8 @@ __device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val)
 //    and at 60 such loads per wave it, not the ALU, was bounding the transform;
 //  * otherwise (the top levels, whose tables are 8 KiB..64 KiB): buffer loads, L2-served.
 constexpr int TWL_LO = 16, TWL_HI = 512;              // LDS-resident table entries [lo, hi)
-constexpr int twl_words(int n) { return n > TWL_LO ? 2 * ((n < TWL_HI ? n : TWL_HI) - TWL_LO) : 0; }
+constexpr int TWL_MIN_L = 11;                         // smaller polynomials: the copy costs more than it saves
+constexpr int twl_words(int n) { return n >= (1 << TWL_MIN_L) ? 2 * (TWL_HI - TWL_LO) : 0; }
 
 struct TwCtx {
   rsrc_t fwd, inv;
@@ -297,7 +298,7 @@ __device__ __forceinline__ void tw_fetch(LevelTw& t, const TwCtx& tw, int xt) {
       const int cidx = level_tab<A, K>.cidx[e];
       if constexpr (tw_uniform<A, K>()) {
         t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
-      } else if constexpr ((2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
+      } else if constexpr (A.ntb + R >= TWL_MIN_L && (2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
         const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1))));
         t.w[ord] = r.x; t.wp[ord] = r.y;
       } else {
@@ -437,6 +438,14 @@ __device__ __forceinline__ void fetch4(LevelTw (&t)[R], const TwCtx& tw, int xt)
   if constexpr (K0 <= 2) tw_fetch<INV, A, 2>(t[2], tw, xt);
   if constexpr (K0 <= 3) tw_fetch<INV, A, 3>(t[3], tw, xt);
 }
+// register-lean variant: fetch each level's twiddles right before the level (<= 32 VGPRs live)
+template <bool APPROX, Lay A, int K0>
+__device__ __forceinline__ void levels4_jit(u64 (&v)[E], const TwCtx& tw, int xt, const QK& qk) {
+  if constexpr (K0 <= 0) { LevelTw t; tw_fetch<false, A, 0>(t, tw, xt); level<APPROX, false, A, 0>(v, t, tw, qk); }
+  if constexpr (K0 <= 1) { LevelTw t; tw_fetch<false, A, 1>(t, tw, xt); level<APPROX, false, A, 1>(v, t, tw, qk); }
+  if constexpr (K0 <= 2) { LevelTw t; tw_fetch<false, A, 2>(t, tw, xt); level<APPROX, false, A, 2>(v, t, tw, qk); }
+  if constexpr (K0 <= 3) { LevelTw t; tw_fetch<false, A, 3>(t, tw, xt); level<APPROX, false, A, 3>(v, t, tw, qk); }
+}
 template <bool APPROX, bool INV, Lay A, int K0>
 __device__ __forceinline__ void levels4(u64 (&v)[E], const LevelTw (&t)[R], const TwCtx& tw, const QK& qk) {
   if constexpr (!INV) {
@@ -452,51 +461,77 @@ __device__ __forceinline__ void levels4(u64 (&v)[E], const LevelTw (&t)[R], cons
   }
 }
 
-// forward transform; data arrives in registers in layout PREV, leaves in Sched<L>::final_layout()
-template <bool APPROX, int L, Lay PREV, int SB = 0>
+// forward transform; data arrives in registers in layout PREV, leaves in Sched<L>::final_layout().
+// LEAN: the caller keeps 32 more VGPRs live (a-hat during b's transform in the fused poly-mul),
+// so twiddles are fetched level by level instead of a pass ahead.
+template <bool APPROX, int L, Lay PREV, int SB = 0, bool LEAN = false>
 __device__ __forceinline__ void fwd_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
   using S = Sched<L>;
   {   // W0: levels 1..4
     constexpr Lay A = S::w0();
-    LevelTw t[R];
     // the previous transform's cross-wave reads may still be in flight in other waves
     if constexpr (S::HAS_G && !lay_eq(PREV, A)) __syncthreads();
     transpose_put<PREV, A, false>(v, lds, tau);
-    fetch4<APPROX, false, A, 0>(t, tw, xthr<A>(tau));
-    transpose_get<PREV, A, false>(v, lds, tau);
-    LH_STAMP(SB + 2);
-    levels4<APPROX, false, A, 0>(v, t, tw, qk);
-    LH_STAMP(SB + 3);
+    if constexpr (LEAN) {
+      transpose_get<PREV, A, false>(v, lds, tau);
+      levels4_jit<APPROX, A, 0>(v, tw, xthr<A>(tau), qk);
+    } else {
+      LevelTw t[R];
+      fetch4<APPROX, false, A, 0>(t, tw, xthr<A>(tau));
+      transpose_get<PREV, A, false>(v, lds, tau);
+      LH_STAMP(SB + 2);
+      levels4<APPROX, false, A, 0>(v, t, tw, qk);
+      LH_STAMP(SB + 3);
+    }
   }
   if constexpr (S::HAS_W1) {   // W1: levels 5..8 (or the window), then lane swaps for 9, 10
     constexpr Lay A = S::w1();
-    LevelTw t[R];
-    transpose_put<S::w0(), A, false>(v, lds, tau);
-    fetch4<APPROX, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
-    transpose_get<S::w0(), A, false>(v, lds, tau);
-    LH_STAMP(SB + 4);
-    // levels 5..8, with the twiddles of the two lane-swap levels fetched as registers free up
-    if constexpr (S::W1_K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
-    if constexpr (S::W1_K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
-    if constexpr (S::W1_K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
-    LevelTw ua, ub;
-    if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
-    level<APPROX, false, A, 3>(v, t[3], tw, qk);
-    LH_STAMP(SB + 5);
-    if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
-    if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, ua, tw, qk); }
-    if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, ub, tw, qk); }
-    LH_STAMP(SB + 6);
+    if constexpr (LEAN) {
+      transpose_put<S::w0(), A, false>(v, lds, tau);
+      transpose_get<S::w0(), A, false>(v, lds, tau);
+      levels4_jit<APPROX, A, S::W1_K0>(v, tw, xthr<A>(tau), qk);
+      if constexpr (S::NSWAP >= 1) {
+        LevelTw u; tw_fetch<false, S::w1a(), 3>(u, tw, xthr<S::w1a()>(tau));
+        lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, u, tw, qk);
+      }
+      if constexpr (S::NSWAP >= 2) {
+        LevelTw u; tw_fetch<false, S::w1b(), 2>(u, tw, xthr<S::w1b()>(tau));
+        lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, u, tw, qk);
+      }
+    } else {
+      LevelTw t[R];
+      transpose_put<S::w0(), A, false>(v, lds, tau);
+      fetch4<APPROX, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
+      transpose_get<S::w0(), A, false>(v, lds, tau);
+      LH_STAMP(SB + 4);
+      // levels 5..8, with the twiddles of the two lane-swap levels fetched as registers free up
+      if constexpr (S::W1_K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
+      if constexpr (S::W1_K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
+      if constexpr (S::W1_K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
+      LevelTw ua, ub;
+      if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
+      level<APPROX, false, A, 3>(v, t[3], tw, qk);
+      LH_STAMP(SB + 5);
+      if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
+      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, ua, tw, qk); }
+      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, ub, tw, qk); }
+      LH_STAMP(SB + 6);
+    }
   }
   if constexpr (S::HAS_G) {    // the one cross-wave exchange, then levels 11..L
     constexpr Lay A = S::g();
-    LevelTw t[R];
     transpose_put<S::wave_end(), A, false>(v, lds, tau);   // writes stay inside the wave's own block
-    fetch4<APPROX, false, A, S::G_K0>(t, tw, xthr<A>(tau));
-    transpose_get<S::wave_end(), A, true>(v, lds, tau);    // barrier, then read across blocks
-    LH_STAMP(SB + 7);
-    levels4<APPROX, false, A, S::G_K0>(v, t, tw, qk);
-    LH_STAMP(SB + 8);
+    if constexpr (LEAN) {
+      transpose_get<S::wave_end(), A, true>(v, lds, tau);  // barrier, then read across blocks
+      levels4_jit<APPROX, A, S::G_K0>(v, tw, xthr<A>(tau), qk);
+    } else {
+      LevelTw t[R];
+      fetch4<APPROX, false, A, S::G_K0>(t, tw, xthr<A>(tau));
+      transpose_get<S::wave_end(), A, true>(v, lds, tau);
+      LH_STAMP(SB + 7);
+      levels4<APPROX, false, A, S::G_K0>(v, t, tw, qk);
+      LH_STAMP(SB + 8);
+    }
   }
 }
 
@@ -596,7 +631,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   // levels 5..9 read their twiddles from LDS; (re)filled before the transform direction changes.
   // Visibility: for L > 10 a workgroup barrier follows before first use; for L <= 10 the
   // polynomial's own wave does both the fill and the reads.
-  if constexpr (L > 4) tw_fill_lds<NT>(lds_tw, (MODE == 1) ? tw.inv : tw.fwd, tw.comp, n, tau);
+  if constexpr (L >= TWL_MIN_L) tw_fill_lds<NT>(lds_tw, (MODE == 1) ? tw.inv : tw.fwd, tw.comp, n, tau);
   tw.sc0 = scale[(size_t)t * 2];
   tw.sc1 = scale[(size_t)t * 2 + 1];
 
@@ -626,34 +661,30 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     if constexpr (MODE == 0) LH_STAMP(20);
   }
   if constexpr (MODE == 2) {
-    // a-hat does not fit in registers next to b's transform at 4 waves/SIMD, and LDS is
-    // full: park it (canonical) in the output rows this workgroup owns — each thread
-    // re-reads exactly the words it wrote, normally still in L2.  The host passes the
-    // operand that aliases c (if any) as `a`, so nothing unread is overwritten.
+    // a-hat stays in registers (canonical) while b is transformed with the register-lean
+    // twiddle schedule; nothing is parked in HBM, and c may alias a and/or b freely because
+    // both operands are fully read before the first store to c.
+    u64 va[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, canon_fwd<APPROX>(v[e], qk));
-    __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < E; ++e) va[e] = canon_fwd<APPROX>(v[e], qk);
     LH_STAMP(9);
     const bool square = (a_in == b_in);
     if (!square) {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk.q);
       LH_STAMP(11);
-      fwd_transform<APPROX, L, LIO, 10>(v, lds, tw, tau, qk);
+      fwd_transform<APPROX, L, LIO, 10, true>(v, lds, tw, tau, qk);
     }
-    __builtin_amdgcn_sched_barrier(0);
     LH_STAMP(19);
     // a-hat is canonical, b-hat may stay lazy (< 8q): the product is still < q * 2^64
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const u64 ah = load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8);
-      const u64 bh = square ? ah : (APPROX ? v[e] : canon_fwd<APPROX>(v[e], qk));
-      v[e] = mulmod(ah, bh, mc);
-      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      const u64 bh = square ? va[e] : (APPROX ? v[e] : canon_fwd<APPROX>(v[e], qk));
+      v[e] = mulmod(va[e], bh, mc);
     }
     LH_STAMP(22);
   }
-  if constexpr (MODE == 2 && L > 4) {
+  if constexpr (MODE == 2 && L >= TWL_MIN_L) {
     // every wave is past its last forward use of the LDS twiddles (the cross-wave barrier of
     // the final forward stage, or program order inside a wave): switch the copy to the inverse table
     if constexpr (L > 10) __syncthreads();
