@@ -166,11 +166,19 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
   if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
-  // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.
+  // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp
+  // lives in the plan and only grows (no allocation or sync on the steady-state path; calls on
+  // one plan must be stream-ordered, as with any workspace).
   const size_t bytes = sizeof(int64_t) * (size_t)(B * P.n * P.T);
   if (bytes == 0) return LOLHIP_OK;
-  int64_t* tmp = nullptr;
-  if (hipMalloc((void**)&tmp, bytes) != hipSuccess) return LOLHIP_ERR_HIP;
+  if (P.tmp_bytes < bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return LOLHIP_ERR_HIP;
+    if (P.d_tmp) (void)hipFree(P.d_tmp);
+    P.d_tmp = nullptr; P.tmp_bytes = 0;
+    if (hipMalloc((void**)&P.d_tmp, bytes) != hipSuccess) return LOLHIP_ERR_HIP;
+    P.tmp_bytes = bytes;
+  }
+  int64_t* tmp = P.d_tmp;
   rc = LOLHIP_OK;
   if (hipMemcpyAsync(tmp, b, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
   if (!rc && c != a && hipMemcpyAsync(c, a, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
@@ -178,8 +186,6 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   if (!rc) rc = run_prog(P, P.prog_crt, s, tmp, B);
   if (!rc) rc = lolhip_mul_batch(p, stream, c, tmp, B);
   if (!rc) rc = run_prog(P, P.prog_crtinv, s, c, B);
-  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = LOLHIP_ERR_HIP;
-  (void)hipFree(tmp);
   return rc;
 }
 

@@ -772,7 +772,14 @@ __device__ __forceinline__ u64 dot_reduce(unsigned __int128 acc, const ModCtx& m
   return reduce128((u64)(acc >> 64), (u64)acc, mc);
 }
 
+// k mod q for a small constant k (almost always k < q: skip the 64-bit division)
+__device__ __forceinline__ u64 smallmod(u64 k, u64 q) { return k < q ? k : k % q; }
+// x / v for x < 2^20 with M = floor(2^40/v)+1 (integer division is ~40 instructions on this ISA)
+template <bool MAGIC> __device__ __forceinline__ int fdiv(int x, u64 M, int v) {
+  if constexpr (MAGIC) return (int)(((u64)(u32)x * M) >> 40); else return x / v;
+}
 // out-of-place evaluation of one output element of one stage
+template <bool MAGIC>
 __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict__ in, int x,
                                           const u64* __restrict__ cst, const ModCtx& mc) {
   const u64 q = mc.q;
@@ -783,29 +790,25 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
     return mulmod(in[x], cst[st.tw_off], mc);
   } else {
     const int rts = st.rts, d = st.d, p = st.p;
-    const int i = (x / rts) % d;
+    const int xb = fdiv<MAGIC>(x, st.m_rts, rts);
+    const int i = xb - fdiv<MAGIC>(xb, st.m_d, d) * d;
     const u64* vin = in + (x - i * rts);
     switch (st.kind) {
       case ST_DFTP:
       case ST_CRTP:
       case ST_CRTPINV: {
-        const u64* wp = cst + st.wp_off;
-        unsigned __int128 acc = 0, sh = 0;
-        u64 part = 0, spart = 0;
+        const u64* row = cst + st.mat_off + i * d;      // dense matrix row (plan.cpp)
+        unsigned __int128 acc = 0;
+        u64 part = 0;
         int cnt = 0;
         for (int c = 0; c < d; ++c) {
-          const u64 xc = vin[c * rts];
-          int widx = (st.kind == ST_DFTP) ? (c * i) % p : (st.kind == ST_CRTP) ? (c * (i + 1)) % p : (i * (c + 1)) % p;
-          acc += (unsigned __int128)xc * wp[widx];
-          if (st.kind == ST_CRTPINV) sh += (unsigned __int128)xc * wp[p - c - 1];
+          acc += (unsigned __int128)vin[c * rts] * row[c];
           if (++cnt == 8) {   // 8 products of < 2^124 fit in 128 bits
             part = addmod(part, dot_reduce(acc, mc), q); acc = 0;
-            if (st.kind == ST_CRTPINV) { spart = addmod(spart, dot_reduce(sh, mc), q); sh = 0; }
             cnt = 0;
           }
         }
-        out = addmod(part, dot_reduce(acc, mc), q);
-        if (st.kind == ST_CRTPINV) out = submod(out, addmod(spart, dot_reduce(sh, mc), q), q);
+        out = cnt ? addmod(part, dot_reduce(acc, mc), q) : part;
         break;
       }
       case ST_L: {
@@ -838,27 +841,31 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
         for (int c = 0; c < d; ++c) {
           if (c <= i) le = addmod(le, vin[c * rts], q); else re = addmod(re, vin[c * rts], q);
         }
-        out = submod(mulmod((u64)(p - 1 - i) % q, le, mc), mulmod((u64)(i + 1) % q, re, mc), q);
+        out = submod(mulmod(smallmod((u64)(p - 1 - i), q), le, mc), mulmod(smallmod((u64)(i + 1), q), re, mc), q);
         break;
       }
       case ST_GINVDEC: {
         u64 s = 0, hi = 0;
         for (int c = 0; c < d; ++c) {
-          s = addmod(s, mulmod((u64)(c + 1) % q, vin[c * rts], mc), q);
+          s = addmod(s, mulmod(smallmod((u64)(c + 1), q), vin[c * rts], mc), q);
           if (c > i) hi = addmod(hi, vin[c * rts], q);
         }
-        out = submod(s, mulmod((u64)p % q, hi, mc), q);
+        out = submod(s, mulmod(smallmod((u64)p, q), hi, mc), q);
         break;
       }
       default:
         out = in[x];
     }
   }
-  if (st.tw_off >= 0) out = mulmod(out, cst[st.tw_off + (x / st.tw_div) % st.tw_mod], mc);
+  if (st.tw_off >= 0) {
+    const int xd = fdiv<MAGIC>(x, st.m_twdiv, st.tw_div);
+    out = mulmod(out, cst[st.tw_off + xd - fdiv<MAGIC>(xd, st.m_twmod, st.tw_mod) * st.tw_mod], mc);
+  }
   return out;
 }
 
-__global__ void __launch_bounds__(256)
+template <bool MAGIC>
+__global__ void __launch_bounds__(1024)
 k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
           const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw,
           u64* __restrict__ scratch, i64 ngroups) {
@@ -872,6 +879,7 @@ k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ st
     const int tot = np * n;
     const ModCtx mc = mod[t];
     const u64* cst = consts + (size_t)t * cpc;
+    const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
     u64* bufA;
     u64* bufB;
     if (scratch) {
@@ -887,8 +895,8 @@ k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ st
     for (int s = 0; s < nstages; ++s) {
       const Stage st = stages[s];
       for (int x = threadIdx.x; x < tot; x += blockDim.x) {
-        const int pi = x / n, xi = x - pi * n;
-        bufB[x] = stage_eval(st, bufA + pi * n, xi, cst, mc);
+        const int pi = fdiv<MAGIC>(x, n_magic, n), xi = x - pi * n;
+        bufB[x] = stage_eval<MAGIC>(st, bufA + pi * n, xi, cst, mc);
       }
       __syncthreads();
       u64* tmp = bufA; bufA = bufB; bufB = tmp;
@@ -916,12 +924,14 @@ hipError_t launch_generic(const GenericLaunch& a) {
     if (grid > 65536) grid = 65536;
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
       if (e != hipSuccess) return e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_generic, dim3((unsigned)grid), dim3(256), lds_bytes, a.stream, a.y, a.B, a.T, (int)a.n,
+    // a workgroup that fills a CU's LDS on its own should also fill its SIMDs
+    const int threads = ((size_t)ppw * a.n >= 4096) ? 1024 : ((size_t)ppw * a.n >= 1024 ? 512 : 256);
+    hipLaunchKernelGGL(k_generic<true>, dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.B, a.T, (int)a.n,
                        a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, scratch, ngroups);
   } else {
     if (!a.scratch) return hipErrorInvalidValue;
@@ -929,8 +939,12 @@ hipError_t launch_generic(const GenericLaunch& a) {
     const i64 maxg = (i64)(a.scratch_bytes / (2 * (size_t)a.n * sizeof(u64)));
     if (grid > maxg) grid = maxg;
     if (grid < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_generic, dim3((unsigned)grid), dim3(256), 0, a.stream, a.y, a.B, a.T, (int)a.n,
-                       a.stages, a.nstages, a.consts, a.cpc, a.mod, 1, a.scratch, a.B);
+    if (a.n < (1 << 20))
+      hipLaunchKernelGGL(k_generic<true>, dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
+                         a.stages, a.nstages, a.consts, a.cpc, a.mod, 1, a.scratch, a.B);
+    else
+      hipLaunchKernelGGL(k_generic<false>, dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
+                         a.stages, a.nstages, a.consts, a.cpc, a.mod, 1, a.scratch, a.B);
   }
   return hipGetLastError();
 }

@@ -31,7 +31,7 @@ struct ProgBuilder {
     Stage s;
     std::memset(&s, 0, sizeof(s));
     s.kind = kind; s.p = p; s.d = d; s.rts = (int32_t)rts; s.wp_off = wp_off;
-    s.tw_off = -1; s.tw_mod = 1; s.tw_div = 1;
+    s.tw_off = -1; s.tw_mod = 1; s.tw_div = 1; s.mat_off = -1;
     st.push_back(s);
   }
   // a diagonal between two stages is folded into the stage before it
@@ -42,7 +42,7 @@ struct ProgBuilder {
     }
     Stage s;
     std::memset(&s, 0, sizeof(s));
-    s.kind = ST_DIAG; s.p = 1; s.d = 1; s.rts = 1; s.wp_off = 0;
+    s.kind = ST_DIAG; s.p = 1; s.d = 1; s.rts = 1; s.wp_off = 0; s.mat_off = -1;
     s.tw_off = tw_off; s.tw_div = (int32_t)tw_div; s.tw_mod = (int32_t)tw_mod;
     st.push_back(s);
   }
@@ -152,6 +152,10 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   for (int t = 0; t < T; ++t) P.oddrad_inv[(size_t)t] = invmod(odd_rad(pps) % qs[(size_t)t], qs[(size_t)t]);
 
   // ---- generic stage programs + constant pool ---------------------------------
+  auto magic40 = [](i64 v) -> uint64_t { return (uint64_t)(((unsigned __int128)1 << 40) / (uint64_t)(v > 0 ? v : 1)) + 1; };
+  auto finish = [&](std::vector<Stage>& st) {
+    for (auto& s : st) { s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod); }
+  };
   PoolBuilder pool(T);
   {  // slot 0: the constant 1 (keeps offsets non-negative and gives an identity diagonal)
     std::vector<std::vector<u64>> one((size_t)T, std::vector<u64>(1));
@@ -178,6 +182,19 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
           RuView r{rutab, T, t};
           for (int j = 0; j < p; ++j) o[(size_t)j] = r(j * mprime);
         }, (size_t)p);
+        // dense coefficient matrices, so the kernel does no index arithmetic per term:
+        //   DFT_p[i][c] = w^(c*i)               (crt.cpp:226-245)
+        //   CRT_p[i][c] = w^(c*(i+1))           (crt.cpp:324-345)
+        //   CRT_p^-1[i][c] = w^(i*(c+1)) - w^(p-c-1)   (crt.cpp:433-456, the shift folded in)
+        auto wpow = [&](int t, i64 ex) { RuView r{rutab, T, t}; return r((ex % p) * mprime); };
+        const int mat_dft = per_comp([&](int t, std::vector<u64>& o) {
+          for (int i = 0; i < p; ++i) for (int c = 0; c < p; ++c) o[(size_t)(i * p + c)] = wpow(t, (i64)c * i);
+        }, (size_t)p * p);
+        const int mat_crt = (p == 2) ? -1 : per_comp([&](int t, std::vector<u64>& o) {
+          const u64 q = qs[(size_t)t];
+          for (int i = 0; i < p - 1; ++i) for (int c = 0; c < p - 1; ++c)
+            o[(size_t)(i * (p - 1) + c)] = inv ? (wpow(t, (i64)i * (c + 1)) + q - wpow(t, p - c - 1)) % q : wpow(t, (i64)c * (i + 1));
+        }, (size_t)(p - 1) * (p - 1));
         // crtTwiddle diagonal over the phi(pp) digit (crt.cpp:35-81)
         int ctw_off = -1;
         if (mprime > 1)
@@ -201,13 +218,13 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
           }, (size_t)dim);
         };
         if (!inv) {
-          if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off);
+          if (p != 2) { pb.dense(ST_CRTP, p, p - 1, rts, wp_off); pb.st.back().mat_off = mat_crt; }
           if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
           i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
           int ecur = e1;
           for (int i = 0; i < e1; ++i) {
             const i64 rtsDim = rts1 * rtsScale;
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off);
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off); pb.st.back().mat_off = mat_dft;
             int off = dft_diag(ecur, ltsScale * p, twidRuStride);
             if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
             ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
@@ -219,11 +236,11 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
             const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
             int off = dft_diag(ecur, ltsScaleP, twidRuStride);
             if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off);
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off); pb.st.back().mat_off = mat_dft;
             ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
           }
           if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
-          if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off);
+          if (p != 2) { pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off); pb.st.back().mat_off = mat_crt; }
         }
       }
       rts *= phi;
@@ -243,8 +260,10 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
       rts *= totient_pp(p, e);
     }
     if (scale) pb.diag(orad_off, 1, 1);
+    finish(pb.st);
     return pb.st;
   };
+  finish(crt.st); finish(crtinv.st);
   P.prog_crt.stages = crt.st;
   P.prog_crtinv.stages = crtinv.st;
   P.prog_l.stages = prime_prog(ST_L, false);
@@ -333,7 +352,8 @@ int plan_upload(Plan& P) {
 
 void plan_free_device(Plan& P) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_scratch);
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_scratch); fr(P.d_tmp);
+  P.d_tmp = nullptr; P.tmp_bytes = 0;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }

@@ -38,8 +38,10 @@ struct Stage {
   int32_t tw_off;   // offset of diagonal table or -1
   int32_t tw_mod;   // diagonal index = (x / tw_div) % tw_mod
   int32_t tw_div;
-  int32_t tw_pre;   // 1: multiply the INPUT element by tw (inverse transforms); 0: the output
+  int32_t mat_off;  // offset of the d x d coefficient matrix (DFTP/CRTP/CRTPINV), row-major
   int32_t pad[3];
+  // multiply-shift reciprocals (floor(2^40/v)+1) of rts, d, tw_div, tw_mod: x/v = (x*M)>>40 for x < 2^20
+  uint64_t m_rts, m_d, m_twdiv, m_twmod;
 };
 
 struct StageProgram {
@@ -83,6 +85,8 @@ struct Plan {
   i64* d_ginvcrt = nullptr;                 // [n*T]
   Pow2Tables pow2;
   bool is_pow2 = false;
+  mutable i64* d_tmp = nullptr;             // operand copy for the unfused (generic-m) poly-mul, grown on demand
+  mutable size_t tmp_bytes = 0;
   u64* d_scratch = nullptr;                 // ping-pong space for polynomials too large for LDS
   size_t scratch_bytes = 0;
 };
