@@ -46,6 +46,9 @@ namespace lolhip {
 
 constexpr int R = 4;
 constexpr int E = 1 << R;
+#ifndef LOLHIP_PAIRED
+#define LOLHIP_PAIRED 0   // measured: hand-interleaving two butterflies is 5% SLOWER (more live VGPRs); kept for A/B
+#endif
 
 // Diagnostic build (-DLOLHIP_STAMPS): per-wave s_memtime stamps at phase boundaries, written
 // to a side buffer nobody else reads.  Never enabled in the shipped library.
@@ -178,6 +181,21 @@ __device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, const QK
     X = csub(s, k.q2);
     Y = shoup_lazy(d, w, wp, k.q);
   }
+}
+// two forward / inverse butterflies at once (APPROX arithmetic), multiplies interleaved
+__device__ __forceinline__ void bfly_fwd2(u64& X1, u64& Y1, u64 w1, u64 wp1, u64& X2, u64& Y2, u64 w2, u64 wp2, const QK& k) {
+  const u64 x1 = csubn(X1, k.nq4), x2 = csubn(X2, k.nq4);
+  u64 n1, n2;
+  shoup_acc2(Y1, w1, wp1, x1, Y2, w2, wp2, x2, k.nq, n1, n2);
+  const u64 z1 = shl1_add64(x1, k.q4), z2 = shl1_add64(x2, k.q4);
+  X1 = n1; Y1 = z1 - n1;
+  X2 = n2; Y2 = z2 - n2;
+}
+__device__ __forceinline__ void bfly_inv2(u64& X1, u64& Y1, u64 w1, u64 wp1, u64& X2, u64& Y2, u64 w2, u64 wp2, const QK& k) {
+  const u64 s1 = add64(X1, Y1), s2 = add64(X2, Y2);
+  const u64 d1 = add64(X1, k.q4) - Y1, d2 = add64(X2, k.q4) - Y2;
+  X1 = csubn(s1, k.nq4); X2 = csubn(s2, k.nq4);
+  shoup_acc2(d1, w1, wp1, 0, d2, w2, wp2, 0, k.nq, Y1, Y2);
 }
 // last inverse level: both outputs additionally scaled by mhat^-1 (crt.cpp:573-579).
 // (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
@@ -325,6 +343,21 @@ __device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx
   for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(t.w[s]), "v"(t.wp[s]));
   return;
 #endif
+#if LOLHIP_PAIRED
+  if constexpr (APPROX && !(INV && beta == 0)) {
+    // the 8 butterflies of a level, two at a time
+    constexpr int KP = (K == 0) ? 1 : 0;          // a register bit other than K: pairs e with e | 1<<KP
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if ((e & (1 << K)) || (e & (1 << KP))) continue;
+      const int f = e | (1 << KP);
+      const int s1 = level_tab<A, K>.slot[e], s2 = level_tab<A, K>.slot[f];
+      if constexpr (!INV) bfly_fwd2(v[e], v[e | (1 << K)], t.w[s1], t.wp[s1], v[f], v[f | (1 << K)], t.w[s2], t.wp[s2], qk);
+      else bfly_inv2(v[e], v[e | (1 << K)], t.w[s1], t.wp[s1], v[f], v[f | (1 << K)], t.w[s2], t.wp[s2], qk);
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
@@ -367,6 +400,9 @@ __device__ __forceinline__ void transpose_put(u64 (&v)[E], u64* lds, int tau) {
   return;
 #endif
   if constexpr (!lay_eq(A, B)) {
+#ifdef LOLHIP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     u64* wp = lds + lpad(xthr<A>(tau));
 #pragma unroll
@@ -383,6 +419,9 @@ __device__ __forceinline__ void transpose_get(u64 (&v)[E], u64* lds, int tau) {
     const u64* rp = lds + lpad(xthr<B>(tau));
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = rp[lpad(lay_tab<B>.xr[e])];
+#ifdef LOLHIP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 }
 
