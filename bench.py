@@ -80,12 +80,16 @@ def cpu_baseline(q: int, budget_s: float = 12.0):
         pool.map(_cpu_worker, [(q, count, 100 + i, kind) for i in range(cores)])
     wall = time.perf_counter() - t0
     # the pool wall time includes process start-up; use it (conservative for the GPU ratio)
+    # the same workload at a modulus where lol-cpp is itself CORRECT (q < 2^31.5): same n, same code
+    q30 = 1073872897
+    t30 = _cpu_worker((q30, 3, 2, kind)) / 3
     return {
         "value": round(cores * count / wall, 2),
         "unit": "poly-muls/s",
         "cores": cores,
         "kind": kind,
         "single_core_ms_per_polymul": round(t1 * 1e3, 3),
+        "single_core_ms_per_polymul_q30": round(t30 * 1e3, 3),
         "sample": (f"{cores} processes x {count} poly-muls (2 crt + mulRq + crtInv through lol-cpp's C ABI), "
                    f"n=8192, q={q}; timing only at this modulus: lol-cpp's Zq overflows for q > ~2^31.5 "
                    "(types.h:79-84), same instruction stream"),
