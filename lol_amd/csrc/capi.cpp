@@ -75,9 +75,14 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
 int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* a, const int64_t* b, int64_t B) {
   Pow2Launch l;
   l.stream = s; l.y = y; l.a = a; l.b = b; l.B = B; l.T = P.T; l.L = P.pow2.L;
-  l.tw_fwd = P.pow2.d_tw_fwd; l.tw_inv = P.pow2.d_tw_inv; l.scale = P.pow2.d_scale; l.mod = P.d_mod;
-  l.approx = true;
-  for (u64 q : P.qs) if (q >= (1ull << 61)) l.approx = false;
+  l.mod = P.d_mod;
+  if (P.pow2.d_tw_fwd32) {          // every modulus < 2^30: 32-bit arithmetic
+    l.arith = 2; l.tw_fwd = P.pow2.d_tw_fwd32; l.tw_inv = P.pow2.d_tw_inv32; l.scale = P.pow2.d_scale32;
+  } else {
+    l.arith = 1;
+    for (u64 q : P.qs) if (q >= (1ull << 61)) l.arith = 0;
+    l.tw_fwd = P.pow2.d_tw_fwd; l.tw_inv = P.pow2.d_tw_inv; l.scale = P.pow2.d_scale;
+  }
   return launch_pow2(l, mode) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 

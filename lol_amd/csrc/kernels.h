@@ -16,9 +16,9 @@ struct Pow2Launch {
   i64 B;
   int T;
   int L;
-  const u64 *tw_fwd, *tw_inv, *scale;
+  const void *tw_fwd, *tw_inv, *scale;   // Shoup-pair tables: u64 pairs (arith 0/1) or u32 pairs (arith 2)
   const ModCtx* mod;
-  bool approx;       // every modulus < 2^61: 9-multiply approximate-quotient butterflies
+  int arith;         // 2: every modulus < 2^30 (32-bit path); 1: every modulus < 2^61; 0: exact 64-bit
 };
 // mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
 hipError_t launch_pow2(const Pow2Launch& a, int mode);

@@ -15,6 +15,8 @@
 // Layout at the boundary is the reference's: y[(b*n + j)*T + t] (tensor.h:69).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "zq_dev.h"
 
@@ -46,6 +48,9 @@ namespace lolhip {
 
 constexpr int R = 4;
 constexpr int E = 1 << R;
+#ifndef LOLHIP_HALF_LEVELS
+#define LOLHIP_HALF_LEVELS 1
+#endif
 #ifndef LOLHIP_PAIRED
 #define LOLHIP_PAIRED 0   // measured: hand-interleaving two butterflies is 5% SLOWER (more live VGPRs); kept for A/B
 #endif
@@ -140,24 +145,42 @@ template <Lay A> inline constexpr LayTab<A> lay_tab{};
 // register part of every LDS address is an immediate offset
 constexpr int lpad(int x) { return x + (x >> 4); }
 
+// ---- arithmetic flavours, chosen per plan on the host (template parameter AR) -------------
+//  AR = 2 (every q_t < 2^30): 32-bit residues, 32-bit Shoup products (3 multiplies per butterfly),
+//         Harvey's lazy ranges [0,4q) forward / [0,2q) inverse.  This is the reference's own
+//         correct domain (its Zq overflows beyond ~2^31.5, types.h:79-84) and the HBM-bound case.
+//  AR = 1 (every q_t < 2^61): 64-bit residues, Shoup products with the 9-multiply approximate
+//         quotient (shoup_acc, result in [0,4q)); forward values in [0,8q), inverse in [0,4q).
+//  AR = 0 (2^61 <= q_t < 2^62): 10-multiply exact quotient, ranges [0,4q) / [0,2q).
+template <int AR> using VT = std::conditional_t<AR == 2, u32, u64>;
+
 // Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
 struct QK {
   u64 q, nq, q2, nq2, q4, nq4;
   __device__ __forceinline__ explicit QK(u64 q_) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {}
 };
+struct QK32 {
+  u32 q, q2;
+  __device__ __forceinline__ explicit QK32(u64 q_) : q((u32)q_), q2(2 * (u32)q_) {}
+};
+template <int AR> using QKT = std::conditional_t<AR == 2, QK32, QK>;
 
-// Two arithmetic flavours, chosen per plan on the host:
-//  APPROX (every q_t < 2^61): Shoup products with the 9-multiply approximate quotient
-//    (shoup_acc, result in [0,4q)); forward values live in [0,8q), inverse values in [0,4q).
-//  exact  (2^61 <= q_t < 2^62): 10-multiply exact quotient, Harvey's [0,4q) / [0,2q) ranges.
+__device__ __forceinline__ u32 csub32(u32 x, u32 m) { return min(x, x - m); }        // x < 2m
+// w*y mod q in [0,2q) for any 32-bit y
+__device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return w * y - __umulhi(wp, y) * q; }
 
 // forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
-template <bool APPROX>
-__device__ __forceinline__ void bfly_fwd(u64& X, u64& Y, u64 w, u64 wp, const QK& k) {
-  if constexpr (APPROX) {
+template <int AR>
+__device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
+  if constexpr (AR == 2) {
+    const u32 x = csub32(X, k.q2);                    // [0,4q) -> [0,2q)
+    const u32 t = shoup32(Y, w, wp, k.q);
+    X = x + t;
+    Y = x - t + k.q2;
+  } else if constexpr (AR == 1) {
     const u64 x = csubn(X, k.nq4);                    // [0,8q) -> [0,4q)
     const u64 xn = shoup_acc(Y, w, wp, k.nq, x);      // x + t, t in [0,4q)
-    const u64 z = shl1_add64(x, k.q4);                // 2x + 4q
+    const u64 z = shl1_add64u(x, k.q4);                // 2x + 4q
     X = xn;
     Y = z - xn;                                       // x - t + 4q
   } else {
@@ -168,11 +191,16 @@ __device__ __forceinline__ void bfly_fwd(u64& X, u64& Y, u64 w, u64 wp, const QK
   }
 }
 // inverse (Gentleman-Sande) butterfly:  X' = X + Y,  Y' = (X - Y) * w
-template <bool APPROX>
-__device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, const QK& k) {
-  if constexpr (APPROX) {
+template <int AR>
+__device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
+  if constexpr (AR == 2) {
+    const u32 s = X + Y;
+    const u32 d = X - Y + k.q2;
+    X = csub32(s, k.q2);
+    Y = shoup32(d, w, wp, k.q);
+  } else if constexpr (AR == 1) {
     const u64 s = add64(X, Y);                        // [0,8q)
-    const u64 d = add64(X, k.q4) - Y;                 // (0,8q)
+    const u64 d = add64u(X, k.q4) - Y;                 // (0,8q)
     X = csubn(s, k.nq4);
     Y = shoup_acc(d, w, wp, k.nq, 0);
   } else {
@@ -182,28 +210,18 @@ __device__ __forceinline__ void bfly_inv(u64& X, u64& Y, u64 w, u64 wp, const QK
     Y = shoup_lazy(d, w, wp, k.q);
   }
 }
-// two forward / inverse butterflies at once (APPROX arithmetic), multiplies interleaved
-__device__ __forceinline__ void bfly_fwd2(u64& X1, u64& Y1, u64 w1, u64 wp1, u64& X2, u64& Y2, u64 w2, u64 wp2, const QK& k) {
-  const u64 x1 = csubn(X1, k.nq4), x2 = csubn(X2, k.nq4);
-  u64 n1, n2;
-  shoup_acc2(Y1, w1, wp1, x1, Y2, w2, wp2, x2, k.nq, n1, n2);
-  const u64 z1 = shl1_add64(x1, k.q4), z2 = shl1_add64(x2, k.q4);
-  X1 = n1; Y1 = z1 - n1;
-  X2 = n2; Y2 = z2 - n2;
-}
-__device__ __forceinline__ void bfly_inv2(u64& X1, u64& Y1, u64 w1, u64 wp1, u64& X2, u64& Y2, u64 w2, u64 wp2, const QK& k) {
-  const u64 s1 = add64(X1, Y1), s2 = add64(X2, Y2);
-  const u64 d1 = add64(X1, k.q4) - Y1, d2 = add64(X2, k.q4) - Y2;
-  X1 = csubn(s1, k.nq4); X2 = csubn(s2, k.nq4);
-  shoup_acc2(d1, w1, wp1, 0, d2, w2, wp2, 0, k.nq, Y1, Y2);
-}
 // last inverse level: both outputs additionally scaled by mhat^-1 (crt.cpp:573-579).
 // (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
-template <bool APPROX>
-__device__ __forceinline__ void bfly_inv_last(u64& X, u64& Y, u64 w, u64 wp, u64 s0, u64 s1, const QK& k) {
-  if constexpr (APPROX) {
+template <int AR>
+__device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, VT<AR> s0, VT<AR> s1, const QKT<AR>& k) {
+  if constexpr (AR == 2) {
+    const u32 s = X + Y;
+    const u32 d = X - Y + k.q2;
+    X = shoup32(s, s0, s1, k.q);
+    Y = shoup32(d, w, wp, k.q);
+  } else if constexpr (AR == 1) {
     const u64 s = add64(X, Y);
-    const u64 d = add64(X, k.q4) - Y;
+    const u64 d = add64u(X, k.q4) - Y;
     X = shoup_acc(s, s0, s1, k.nq, 0);
     Y = shoup_acc(d, w, wp, k.nq, 0);
   } else {
@@ -213,13 +231,37 @@ __device__ __forceinline__ void bfly_inv_last(u64& X, u64& Y, u64 w, u64 wp, u64
     Y = shoup_lazy(d, w, wp, k.q);
   }
 }
-template <bool APPROX> __device__ __forceinline__ u64 canon_fwd(u64 v, const QK& k) {
-  if constexpr (APPROX) v = csubn(v, k.nq4);
-  return csubn(csubn(v, k.nq2), k.nq);
+template <int AR> __device__ __forceinline__ VT<AR> canon_fwd(VT<AR> v, const QKT<AR>& k) {
+  if constexpr (AR == 2) return csub32(csub32(v, k.q2), k.q);
+  else {
+    if constexpr (AR == 1) v = csubn(v, k.nq4);
+    return csubn(csubn(v, k.nq2), k.nq);
+  }
 }
-template <bool APPROX> __device__ __forceinline__ u64 canon_inv(u64 v, const QK& k) {
-  if constexpr (APPROX) v = csubn(v, k.nq2);
-  return csubn(v, k.nq);
+template <int AR> __device__ __forceinline__ VT<AR> canon_inv(VT<AR> v, const QKT<AR>& k) {
+  if constexpr (AR == 2) return csub32(v, k.q);
+  else {
+    if constexpr (AR == 1) v = csubn(v, k.nq2);
+    return csubn(v, k.nq);
+  }
+}
+// reference-style input in (-q, q) -> [0, q)
+template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR>& k) {
+  if constexpr (AR == 2) return (u32)x + (k.q & (u32)(x >> 63));
+  else return canon_in(x, k.q);
+}
+// pointwise product of a canonical a-hat and a lazy b-hat (forward range), any range the
+// inverse transform accepts
+template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, const ModCtx& mc, const QKT<AR>& k) {
+  if constexpr (AR == 2) {
+    const u64 x = (u64)a * b;                          // < q * 4q < 2^62
+    const u64 Q = __umul64hi(x, mc.mu);                // floor(x/q) or one less
+    return csub32((u32)(x - Q * mc.q), k.q);           // [0,2q) -> [0,q)
+  } else if constexpr (AR == 1) {
+    return mulmod(a, b, mc);                           // a < q, b < 8q: a*b < q * 2^64
+  } else {
+    return mulmod(a, canon_fwd<0>(b, k), mc);
+  }
 }
 
 // Global memory goes through buffer descriptors: address = base (SGPRs) + one 32-bit
@@ -232,6 +274,11 @@ __device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u64&
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tw, voff, const_idx * 16u, 0);
   w = ((u64)r.y << 32) | r.x;
   wp = ((u64)r.w << 32) | r.z;
+}
+__device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u32& w, u32& wp) {
+  const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tw, voff, const_idx * 8u, 0);
+  w = r.x;
+  wp = r.y;
 }
 __device__ __forceinline__ u64 load_u64(rsrc_t r, u32 voff, u32 soff) {
 #ifdef LOLHIP_ABL_NO_IO       // ablation: compute-only timing, results are garbage
@@ -260,12 +307,12 @@ constexpr int TWL_LO = 16, TWL_HI = 512;              // LDS-resident table entr
 constexpr int TWL_MIN_L = 11;                         // smaller polynomials: the copy costs more than it saves
 constexpr int twl_words(int n) { return n >= (1 << TWL_MIN_L) ? 2 * (TWL_HI - TWL_LO) : 0; }
 
-struct TwCtx {
+template <typename V> struct TwCtxT {
   rsrc_t fwd, inv;
-  const u64 *pf, *pi;   // this component's tables as plain pointers (scalar loads)
-  const u64* lds_tw;    // LDS copy of entries [16,512) of the table currently in use
+  const V *pf, *pi;     // this component's tables as plain pointers (scalar loads)
+  const V* lds_tw;      // LDS copy of entries [16,512) of the table currently in use
   u32 comp;             // byte offset of this RNS component's table
-  u64 sc0, sc1;         // Shoup pair of mhat^-1
+  V sc0, sc1;           // Shoup pair of mhat^-1
 };
 template <Lay A, int K> constexpr bool tw_uniform() {
   for (int j = 0; j < A.ntb; ++j) if (A.thr[j] < A.reg[K]) return false;
@@ -282,6 +329,17 @@ constexpr int tw_cidx(const Lay& a, int k, int e) {
   return (1 << beta) + (xreg(a, e) & ((1 << beta) - 1));
 }
 // ordinal (0..7) of the first butterfly of level k that uses the same twiddle as butterfly e
+// number of distinct twiddles of level k in layout a
+constexpr int tw_distinct(const Lay& a, int k) {
+  int cnt = 0;
+  for (int e = 0; e < E; ++e) {
+    if (e & (1 << k)) continue;
+    bool first = true;
+    for (int f = 0; f < e; ++f) if (!(f & (1 << k)) && tw_cidx(a, k, f) == tw_cidx(a, k, e)) first = false;
+    cnt += first ? 1 : 0;
+  }
+  return cnt;
+}
 constexpr int tw_slot(const Lay& a, int k, int e) {
   int ord = 0;
   for (int f = 0; f < E; ++f) {
@@ -296,29 +354,30 @@ template <Lay A, int K> struct LevelTab {
   constexpr LevelTab() : cidx{}, slot{} { for (int e = 0; e < E; ++e) { cidx[e] = tw_cidx(A, K, e); slot[e] = tw_slot(A, K, e); } }
 };
 template <Lay A, int K> inline constexpr LevelTab<A, K> level_tab{};
-struct LevelTw { u64 w[8], wp[8]; };
+template <typename V> struct LevelTwT { V w[8], wp[8]; };
 
-template <bool INV, Lay A, int K>
-__device__ __forceinline__ void tw_fetch(LevelTw& t, const TwCtx& tw, int xt) {
+template <bool INV, Lay A, int K, int HALF = -1, typename V>
+__device__ __forceinline__ void tw_fetch(LevelTwT<V>& t, const TwCtxT<V>& tw, int xt) {
   constexpr int beta = A.reg[K];
 #ifdef LOLHIP_ABL_NO_TW       // ablation: no twiddle traffic
 #pragma unroll
   for (int s = 0; s < 8; ++s) { t.w[s] = tw.sc0 + s; t.wp[s] = tw.sc1 + K; }
   return;
 #endif
-  const u32 voff = tw.comp + (u32)(xt & ((1 << beta) - 1)) * 16u;
-  const u64* sp = INV ? tw.pi : tw.pf;
+  const u32 voff = tw.comp + (u32)(xt & ((1 << beta) - 1)) * (u32)(2 * sizeof(V));
+  const V* sp = INV ? tw.pi : tw.pf;
   int ord = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
-    if (level_tab<A, K>.slot[e] == ord) {
+    if (level_tab<A, K>.slot[e] == ord && (HALF < 0 || (ord >> 2) == HALF)) {
       const int cidx = level_tab<A, K>.cidx[e];
       if constexpr (tw_uniform<A, K>()) {
         t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
       } else if constexpr (A.ntb + R >= TWL_MIN_L && (2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
-        const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1))));
-        t.w[ord] = r.x; t.wp[ord] = r.y;
+        const V* lp = tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1)));
+        if constexpr (sizeof(V) == 8) { const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
+        else { const uint2 r = *reinterpret_cast<const uint2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
       } else {
         load_tw(INV ? tw.inv : tw.fwd, voff, (u32)cidx, t.w[ord], t.wp[ord]);
       }
@@ -327,16 +386,21 @@ __device__ __forceinline__ void tw_fetch(LevelTw& t, const TwCtx& tw, int xt) {
   }
 }
 // copy entries [16, 512) of one component's table into LDS (NT threads of one polynomial)
-template <int NT>
-__device__ __forceinline__ void tw_fill_lds(u64* dst, rsrc_t src, u32 comp, int n, int tau) {
+template <int NT, typename V>
+__device__ __forceinline__ void tw_fill_lds(V* dst, rsrc_t src, u32 comp, int n, int tau) {
   const int cnt = (n < TWL_HI ? n : TWL_HI) - TWL_LO;
   for (int i = tau; i < cnt; i += NT) {
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(src, comp + (u32)(TWL_LO + i) * 16u, 0, 0);
-    *reinterpret_cast<u32x4*>(dst + 2 * i) = r;
+    if constexpr (sizeof(V) == 8) {
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(src, comp + (u32)(TWL_LO + i) * 16u, 0, 0);
+      *reinterpret_cast<u32x4*>(dst + 2 * i) = r;
+    } else {
+      const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(src, comp + (u32)(TWL_LO + i) * 8u, 0, 0);
+      *reinterpret_cast<u32x2*>(dst + 2 * i) = r;
+    }
   }
 }
-template <bool APPROX, bool INV, Lay A, int K>
-__device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx& tw, const QK& qk) {
+template <int AR, bool INV, Lay A, int K, int HALF = -1>
+__device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t, const TwCtxT<VT<AR>>& tw, const QKT<AR>& qk) {
   constexpr int beta = A.reg[K];
 #ifdef LOLHIP_ABL_NO_BFLY     // ablation: keep the twiddles live, skip the arithmetic
 #pragma unroll
@@ -344,7 +408,7 @@ __device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx
   return;
 #endif
 #if LOLHIP_PAIRED
-  if constexpr (APPROX && !(INV && beta == 0)) {
+  if constexpr (AR == 1 && !(INV && beta == 0)) {
     // the 8 butterflies of a level, two at a time
     constexpr int KP = (K == 0) ? 1 : 0;          // a register bit other than K: pairs e with e | 1<<KP
 #pragma unroll
@@ -358,17 +422,34 @@ __device__ __forceinline__ void level(u64 (&v)[E], const LevelTw& t, const TwCtx
     return;
   }
 #endif
+  int ordb = -1;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
+    ++ordb;
+    if (HALF >= 0 && (ordb >> 2) != HALF) continue;
     const int s = level_tab<A, K>.slot[e];
-    if constexpr (!INV) bfly_fwd<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
-    else if constexpr (beta == 0) bfly_inv_last<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
-    else bfly_inv<APPROX>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+    if constexpr (!INV) bfly_fwd<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+    else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
+    else bfly_inv<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
   }
 }
 
 // exchange lane bit TB (4 or 5) with register bit RK: 16 v_permlane*_swap, no LDS
+template <int TB, int RK>
+__device__ __forceinline__ void lane_swap(u32 (&v)[E]) {
+  static_assert(TB == 4 || TB == 5, "only lane bits 4 and 5 have swap instructions");
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (e & (1 << RK)) continue;
+    const int f = e | (1 << RK);
+    u32x2 r;
+    if constexpr (TB == 5) r = __builtin_amdgcn_permlane32_swap(v[e], v[f], false, false);
+    else r = __builtin_amdgcn_permlane16_swap(v[e], v[f], false, false);
+    v[e] = r.x;
+    v[f] = r.y;
+  }
+}
 template <int TB, int RK>
 __device__ __forceinline__ void lane_swap(u64 (&v)[E]) {
   static_assert(TB == 4 || TB == 5, "only lane bits 4 and 5 have swap instructions");
@@ -394,8 +475,8 @@ __device__ __forceinline__ void lane_swap(u64 (&v)[E]) {
 // block) need no s_barrier at all: a wave's LDS instructions execute in order.  Only the one
 // transpose per transform that crosses waves pays two workgroup barriers; the one protecting
 // the previous reads comes FIRST, when every wave has long finished them.
-template <Lay A, Lay B, bool CROSS_WAVE>
-__device__ __forceinline__ void transpose_put(u64 (&v)[E], u64* lds, int tau) {
+template <Lay A, Lay B, bool CROSS_WAVE, typename V>
+__device__ __forceinline__ void transpose_put(V (&v)[E], V* lds, int tau) {
 #ifdef LOLHIP_ABL_NO_XPOSE
   return;
 #endif
@@ -404,19 +485,19 @@ __device__ __forceinline__ void transpose_put(u64 (&v)[E], u64* lds, int tau) {
     __builtin_amdgcn_s_setprio(3);
 #endif
     if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    u64* wp = lds + lpad(xthr<A>(tau));
+    V* wp = lds + lpad(xthr<A>(tau));
 #pragma unroll
     for (int e = 0; e < E; ++e) wp[lpad(lay_tab<A>.xr[e])] = v[e];
   }
 }
-template <Lay A, Lay B, bool CROSS_WAVE>
-__device__ __forceinline__ void transpose_get(u64 (&v)[E], u64* lds, int tau) {
+template <Lay A, Lay B, bool CROSS_WAVE, typename V>
+__device__ __forceinline__ void transpose_get(V (&v)[E], V* lds, int tau) {
 #ifdef LOLHIP_ABL_NO_XPOSE
   return;
 #endif
   if constexpr (!lay_eq(A, B)) {
     if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    const u64* rp = lds + lpad(xthr<B>(tau));
+    const V* rp = lds + lpad(xthr<B>(tau));
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = rp[lpad(lay_tab<B>.xr[e])];
 #ifdef LOLHIP_PRIO
@@ -470,147 +551,168 @@ template <int L> struct Sched {
   static constexpr Lay final_layout() { return HAS_G ? g() : wave_end(); }
 };
 
-template <bool APPROX, bool INV, Lay A, int K0>
-__device__ __forceinline__ void fetch4(LevelTw (&t)[R], const TwCtx& tw, int xt) {
+template <int AR, bool INV, Lay A, int K0>
+__device__ __forceinline__ void fetch4(LevelTwT<VT<AR>> (&t)[R], const TwCtxT<VT<AR>>& tw, int xt) {
   if constexpr (K0 <= 0) tw_fetch<INV, A, 0>(t[0], tw, xt);
   if constexpr (K0 <= 1) tw_fetch<INV, A, 1>(t[1], tw, xt);
   if constexpr (K0 <= 2) tw_fetch<INV, A, 2>(t[2], tw, xt);
   if constexpr (K0 <= 3) tw_fetch<INV, A, 3>(t[3], tw, xt);
 }
 // register-lean variant: fetch each level's twiddles right before the level (<= 32 VGPRs live)
-template <bool APPROX, Lay A, int K0>
-__device__ __forceinline__ void levels4_jit(u64 (&v)[E], const TwCtx& tw, int xt, const QK& qk) {
-  if constexpr (K0 <= 0) { LevelTw t; tw_fetch<false, A, 0>(t, tw, xt); level<APPROX, false, A, 0>(v, t, tw, qk); }
-  if constexpr (K0 <= 1) { LevelTw t; tw_fetch<false, A, 1>(t, tw, xt); level<APPROX, false, A, 1>(v, t, tw, qk); }
-  if constexpr (K0 <= 2) { LevelTw t; tw_fetch<false, A, 2>(t, tw, xt); level<APPROX, false, A, 2>(v, t, tw, qk); }
-  if constexpr (K0 <= 3) { LevelTw t; tw_fetch<false, A, 3>(t, tw, xt); level<APPROX, false, A, 3>(v, t, tw, qk); }
-}
-template <bool APPROX, bool INV, Lay A, int K0>
-__device__ __forceinline__ void levels4(u64 (&v)[E], const LevelTw (&t)[R], const TwCtx& tw, const QK& qk) {
-  if constexpr (!INV) {
-    if constexpr (K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
-    if constexpr (K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
-    if constexpr (K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
-    if constexpr (K0 <= 3) level<APPROX, false, A, 3>(v, t[3], tw, qk);
+template <int AR, bool INV, Lay A, int K>
+__device__ __forceinline__ void level_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
+  using LevelTw = LevelTwT<VT<AR>>;
+  if constexpr (LOLHIP_HALF_LEVELS && tw_distinct(A, K) == 8 && sizeof(VT<AR>) == 8) {
+    // all eight twiddles distinct (32 VGPRs): two halves of four keep the live set small
+    { LevelTw t; tw_fetch<INV, A, K, 0>(t, tw, xt); level<AR, INV, A, K, 0>(v, t, tw, qk); }
+    { LevelTw t; tw_fetch<INV, A, K, 1>(t, tw, xt); level<AR, INV, A, K, 1>(v, t, tw, qk); }
   } else {
-    if constexpr (K0 <= 3) level<APPROX, true, A, 3>(v, t[3], tw, qk);
-    if constexpr (K0 <= 2) level<APPROX, true, A, 2>(v, t[2], tw, qk);
-    if constexpr (K0 <= 1) level<APPROX, true, A, 1>(v, t[1], tw, qk);
-    if constexpr (K0 <= 0) level<APPROX, true, A, 0>(v, t[0], tw, qk);
+    LevelTw t; tw_fetch<INV, A, K>(t, tw, xt); level<AR, INV, A, K>(v, t, tw, qk);
+  }
+}
+template <int AR, Lay A, int K0>
+__device__ __forceinline__ void levels4_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
+  if constexpr (K0 <= 0) level_jit<AR, false, A, 0>(v, tw, xt, qk);
+  if constexpr (K0 <= 1) level_jit<AR, false, A, 1>(v, tw, xt, qk);
+  if constexpr (K0 <= 2) level_jit<AR, false, A, 2>(v, tw, xt, qk);
+  if constexpr (K0 <= 3) level_jit<AR, false, A, 3>(v, tw, xt, qk);
+}
+template <int AR, bool INV, Lay A, int K0>
+__device__ __forceinline__ void levels4(VT<AR> (&v)[E], const LevelTwT<VT<AR>> (&t)[R], const TwCtxT<VT<AR>>& tw, const QKT<AR>& qk) {
+  if constexpr (!INV) {
+    if constexpr (K0 <= 0) level<AR, false, A, 0>(v, t[0], tw, qk);
+    if constexpr (K0 <= 1) level<AR, false, A, 1>(v, t[1], tw, qk);
+    if constexpr (K0 <= 2) level<AR, false, A, 2>(v, t[2], tw, qk);
+    if constexpr (K0 <= 3) level<AR, false, A, 3>(v, t[3], tw, qk);
+  } else {
+    if constexpr (K0 <= 3) level<AR, true, A, 3>(v, t[3], tw, qk);
+    if constexpr (K0 <= 2) level<AR, true, A, 2>(v, t[2], tw, qk);
+    if constexpr (K0 <= 1) level<AR, true, A, 1>(v, t[1], tw, qk);
+    if constexpr (K0 <= 0) level<AR, true, A, 0>(v, t[0], tw, qk);
   }
 }
 
 // forward transform; data arrives in registers in layout PREV, leaves in Sched<L>::final_layout().
 // LEAN: the caller keeps 32 more VGPRs live (a-hat during b's transform in the fused poly-mul),
 // so twiddles are fetched level by level instead of a pass ahead.
-template <bool APPROX, int L, Lay PREV, int SB = 0, bool LEAN = false>
-__device__ __forceinline__ void fwd_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+// An opaque copy of a value: addresses derived from the copy cannot be CSE'd with (and kept
+// live since) an earlier pass's; recomputing a few address adds per pass is far cheaper than
+// a dozen VGPRs held across all three transforms of the fused poly-mul.
+__device__ __forceinline__ int fresh(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false>
+__device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
+  using LevelTw = LevelTwT<VT<AR>>;
   using S = Sched<L>;
   {   // W0: levels 1..4
     constexpr Lay A = S::w0();
+    const int tau = fresh(tau_in);
     // the previous transform's cross-wave reads may still be in flight in other waves
     if constexpr (S::HAS_G && !lay_eq(PREV, A)) __syncthreads();
     transpose_put<PREV, A, false>(v, lds, tau);
     if constexpr (LEAN) {
       transpose_get<PREV, A, false>(v, lds, tau);
-      levels4_jit<APPROX, A, 0>(v, tw, xthr<A>(tau), qk);
+      levels4_jit<AR, A, 0>(v, tw, xthr<A>(tau), qk);
     } else {
       LevelTw t[R];
-      fetch4<APPROX, false, A, 0>(t, tw, xthr<A>(tau));
+      fetch4<AR, false, A, 0>(t, tw, xthr<A>(tau));
       transpose_get<PREV, A, false>(v, lds, tau);
       LH_STAMP(SB + 2);
-      levels4<APPROX, false, A, 0>(v, t, tw, qk);
+      levels4<AR, false, A, 0>(v, t, tw, qk);
       LH_STAMP(SB + 3);
     }
   }
   if constexpr (S::HAS_W1) {   // W1: levels 5..8 (or the window), then lane swaps for 9, 10
     constexpr Lay A = S::w1();
+    const int tau = fresh(tau_in);
     if constexpr (LEAN) {
       transpose_put<S::w0(), A, false>(v, lds, tau);
       transpose_get<S::w0(), A, false>(v, lds, tau);
-      levels4_jit<APPROX, A, S::W1_K0>(v, tw, xthr<A>(tau), qk);
-      if constexpr (S::NSWAP >= 1) {
-        LevelTw u; tw_fetch<false, S::w1a(), 3>(u, tw, xthr<S::w1a()>(tau));
-        lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, u, tw, qk);
-      }
-      if constexpr (S::NSWAP >= 2) {
-        LevelTw u; tw_fetch<false, S::w1b(), 2>(u, tw, xthr<S::w1b()>(tau));
-        lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, u, tw, qk);
-      }
+      levels4_jit<AR, A, S::W1_K0>(v, tw, xthr<A>(tau), qk);
+      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level_jit<AR, false, S::w1a(), 3>(v, tw, xthr<S::w1a()>(tau), qk); }
+      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level_jit<AR, false, S::w1b(), 2>(v, tw, xthr<S::w1b()>(tau), qk); }
     } else {
       LevelTw t[R];
       transpose_put<S::w0(), A, false>(v, lds, tau);
-      fetch4<APPROX, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
+      fetch4<AR, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
       transpose_get<S::w0(), A, false>(v, lds, tau);
       LH_STAMP(SB + 4);
       // levels 5..8, with the twiddles of the two lane-swap levels fetched as registers free up
-      if constexpr (S::W1_K0 <= 0) level<APPROX, false, A, 0>(v, t[0], tw, qk);
-      if constexpr (S::W1_K0 <= 1) level<APPROX, false, A, 1>(v, t[1], tw, qk);
-      if constexpr (S::W1_K0 <= 2) level<APPROX, false, A, 2>(v, t[2], tw, qk);
+      if constexpr (S::W1_K0 <= 0) level<AR, false, A, 0>(v, t[0], tw, qk);
+      if constexpr (S::W1_K0 <= 1) level<AR, false, A, 1>(v, t[1], tw, qk);
+      if constexpr (S::W1_K0 <= 2) level<AR, false, A, 2>(v, t[2], tw, qk);
       LevelTw ua, ub;
       if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
-      level<APPROX, false, A, 3>(v, t[3], tw, qk);
+      level<AR, false, A, 3>(v, t[3], tw, qk);
       LH_STAMP(SB + 5);
       if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
-      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<APPROX, false, S::w1a(), 3>(v, ua, tw, qk); }
-      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<APPROX, false, S::w1b(), 2>(v, ub, tw, qk); }
+      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<AR, false, S::w1a(), 3>(v, ua, tw, qk); }
+      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<AR, false, S::w1b(), 2>(v, ub, tw, qk); }
       LH_STAMP(SB + 6);
     }
   }
   if constexpr (S::HAS_G) {    // the one cross-wave exchange, then levels 11..L
     constexpr Lay A = S::g();
+    const int tau = fresh(tau_in);
     transpose_put<S::wave_end(), A, false>(v, lds, tau);   // writes stay inside the wave's own block
     if constexpr (LEAN) {
       transpose_get<S::wave_end(), A, true>(v, lds, tau);  // barrier, then read across blocks
-      levels4_jit<APPROX, A, S::G_K0>(v, tw, xthr<A>(tau), qk);
+      levels4_jit<AR, A, S::G_K0>(v, tw, xthr<A>(tau), qk);
     } else {
       LevelTw t[R];
-      fetch4<APPROX, false, A, S::G_K0>(t, tw, xthr<A>(tau));
+      fetch4<AR, false, A, S::G_K0>(t, tw, xthr<A>(tau));
       transpose_get<S::wave_end(), A, true>(v, lds, tau);
       LH_STAMP(SB + 7);
-      levels4<APPROX, false, A, S::G_K0>(v, t, tw, qk);
+      levels4<AR, false, A, S::G_K0>(v, t, tw, qk);
       LH_STAMP(SB + 8);
     }
   }
 }
 
 // inverse transform; data arrives in Sched<L>::final_layout(), leaves in layout NEXT
-template <bool APPROX, int L, Lay NEXT>
-__device__ __forceinline__ void inv_transform(u64 (&v)[E], u64* lds, const TwCtx& tw, int tau, const QK& qk) {
+template <int AR, int L, Lay NEXT>
+__device__ __forceinline__ void inv_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
+  using LevelTw = LevelTwT<VT<AR>>;
   using S = Sched<L>;
   if constexpr (S::HAS_G) {
     constexpr Lay A = S::g();
+    const int tau = fresh(tau_in);
     LevelTw t[R];
-    fetch4<APPROX, true, A, S::G_K0>(t, tw, xthr<A>(tau));
-    levels4<APPROX, true, A, S::G_K0>(v, t, tw, qk);
+    fetch4<AR, true, A, S::G_K0>(t, tw, xthr<A>(tau));
+    levels4<AR, true, A, S::G_K0>(v, t, tw, qk);
     transpose_put<A, S::wave_end(), true>(v, lds, tau);    // barrier (earlier readers), write across blocks
   }
   if constexpr (S::HAS_W1) {
     constexpr Lay A = S::w1();
+    const int tau = fresh(tau_in);
     const int xt = xthr<A>(tau);
     LevelTw ua, ub, t[R];
     if constexpr (S::NSWAP >= 2) tw_fetch<true, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
     if constexpr (S::NSWAP >= 1) tw_fetch<true, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
-    if constexpr (S::NSWAP == 0) fetch4<APPROX, true, A, S::W1_K0>(t, tw, xt);
+    if constexpr (S::NSWAP == 0) fetch4<AR, true, A, S::W1_K0>(t, tw, xt);
     if constexpr (S::HAS_G) transpose_get<S::g(), S::wave_end(), true>(v, lds, tau);   // barrier, read own block
-    if constexpr (S::NSWAP >= 2) { level<APPROX, true, S::w1b(), 2>(v, ub, tw, qk); lane_swap<5, 2>(v); }
+    if constexpr (S::NSWAP >= 2) { level<AR, true, S::w1b(), 2>(v, ub, tw, qk); lane_swap<5, 2>(v); }
     if constexpr (S::NSWAP >= 1) {
       tw_fetch<true, A, 3>(t[3], tw, xt);
-      level<APPROX, true, S::w1a(), 3>(v, ua, tw, qk);
+      level<AR, true, S::w1a(), 3>(v, ua, tw, qk);
       lane_swap<4, 3>(v);
       tw_fetch<true, A, 2>(t[2], tw, xt);
       tw_fetch<true, A, 1>(t[1], tw, xt);
       tw_fetch<true, A, 0>(t[0], tw, xt);
     }
-    levels4<APPROX, true, A, S::W1_K0>(v, t, tw, qk);
+    levels4<AR, true, A, S::W1_K0>(v, t, tw, qk);
     transpose_put<A, S::w0(), false>(v, lds, tau);
   }
   {
     constexpr Lay A = S::w0();
+    const int tau = fresh(tau_in);
     LevelTw t[R];
-    fetch4<APPROX, true, A, 0>(t, tw, xthr<A>(tau));
+    fetch4<AR, true, A, 0>(t, tw, xthr<A>(tau));
     if constexpr (S::HAS_W1) transpose_get<S::w1(), A, false>(v, lds, tau);
-    levels4<APPROX, true, A, 0>(v, t, tw, qk);
+    levels4<AR, true, A, 0>(v, t, tw, qk);
     transpose_put<A, NEXT, false>(v, lds, tau);
     transpose_get<A, NEXT, false>(v, lds, tau);
   }
@@ -619,19 +721,21 @@ __device__ __forceinline__ void inv_transform(u64 (&v)[E], u64* lds, const TwCtx
 constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
 
 // MODE 0: crt in place, 1: crtInv in place, 2: c = crtInv(crt(a) * crt(b))
-template <int L, int MODE, bool APPROX>
-__global__ void __launch_bounds__(pow2_threads(L), 4)
+template <int L, int MODE, int AR>
+__global__ void __launch_bounds__(pow2_threads(L), AR == 2 ? 8 : 4)
 k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
-       const u64* __restrict__ tw_fwd, const u64* __restrict__ tw_inv, const u64* __restrict__ scale,
+       const VT<AR>* __restrict__ tw_fwd, const VT<AR>* __restrict__ tw_inv, const VT<AR>* __restrict__ scale,
        const ModCtx* __restrict__ mod, int xcd_map) {
   using S = Sched<L>;
+  using V = VT<AR>;
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);                  // threads per polynomial
   constexpr int PPW = NT >= 256 ? 1 : 256 / NT;     // polynomials per workgroup
-  constexpr int LDSW = n + n / 16 + twl_words(n);   // padded coefficients + twiddle copy, per polynomial
+  constexpr int LDSW = n + n / 16 + twl_words(n);   // padded coefficients + twiddle copy, per polynomial (V words)
+  constexpr u32 TWB = 2 * sizeof(V);                // bytes per twiddle entry
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64* lds = reinterpret_cast<u64*>(smem) + (threadIdx.x / NT) * LDSW;
-  u64* lds_tw = lds + n + n / 16;
+  V* lds = reinterpret_cast<V*>(smem) + (threadIdx.x / NT) * LDSW;
+  V* lds_tw = lds + n + n / 16;
   const int tau = threadIdx.x % NT;
 
   // work item -> (b, t); with xcd_map the T components of one polynomial land on
@@ -649,8 +753,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
-  const ModCtx mc = mod[t];
-  const QK qk(mc.q);
+  const QKT<AR> qk(mod[t].q);
   // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
   // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
   // stores are dropped by the hardware range check.
@@ -660,10 +763,10 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + wbase), 0, wbytes, 0x00020000);
   const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
   const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
-  TwCtx tw;
-  tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * 16u, 0x00020000);
-  tw.inv = __builtin_amdgcn_make_buffer_rsrc((void*)tw_inv, 0, (u32)T * n * 16u, 0x00020000);
-  tw.comp = (u32)t * (u32)n * 16u;
+  TwCtxT<V> tw;
+  tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * TWB, 0x00020000);
+  tw.inv = __builtin_amdgcn_make_buffer_rsrc((void*)tw_inv, 0, (u32)T * n * TWB, 0x00020000);
+  tw.comp = (u32)t * (u32)n * TWB;
   tw.pf = tw_fwd + (size_t)t * n * 2;
   tw.pi = tw_inv + (size_t)t * n * 2;
   tw.lds_tw = lds_tw;
@@ -681,7 +784,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   const u32 off_io = pofs + (u32)xthr<LIO>(tau) * uT8;
   const u32 off_fin = pofs + (u32)xthr<LFIN>(tau) * uT8;
 
-  u64 v[E];
+  V v[E];
   LH_STAMP(0);
 #ifdef LOLHIP_STAMPS
   if (g_stamp_buf && (threadIdx.x & 63) == 0) {
@@ -694,33 +797,36 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   if constexpr (MODE == 0 || MODE == 2) {
     const rsrc_t src = (MODE == 2) ? ra : ry;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk.q);
+    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk);
     LH_STAMP(1);
-    fwd_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+    fwd_transform<AR, L, LIO>(v, lds, tw, tau, qk);
     if constexpr (MODE == 0) LH_STAMP(20);
   }
   if constexpr (MODE == 2) {
     // a-hat stays in registers (canonical) while b is transformed with the register-lean
     // twiddle schedule; nothing is parked in HBM, and c may alias a and/or b freely because
     // both operands are fully read before the first store to c.
-    u64 va[E];
+    V va[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) va[e] = canon_fwd<APPROX>(v[e], qk);
+    for (int e = 0; e < E; ++e) va[e] = canon_fwd<AR>(v[e], qk);
     LH_STAMP(9);
     const bool square = (a_in == b_in);
     if (!square) {
+      u64 raw[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk.q);
+      for (int e = 0; e < E; ++e) raw[e] = load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8);
+      // keep the 16 loads back to back: at this register pressure the scheduler otherwise
+      // sinks each load to its use and the wave pays 16 serial HBM round trips
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)raw[e], qk);
       LH_STAMP(11);
-      fwd_transform<APPROX, L, LIO, 10, true>(v, lds, tw, tau, qk);
+      fwd_transform<AR, L, LIO, 10, true>(v, lds, tw, tau, qk);
     }
     LH_STAMP(19);
-    // a-hat is canonical, b-hat may stay lazy (< 8q): the product is still < q * 2^64
+    const ModCtx mc = mod[t];     // re-read here: keeping it live across the transforms costs registers
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const u64 bh = square ? va[e] : (APPROX ? v[e] : canon_fwd<APPROX>(v[e], qk));
-      v[e] = mulmod(va[e], bh, mc);
-    }
+    for (int e = 0; e < E; ++e) v[e] = pmul<AR>(va[e], square ? va[e] : v[e], mc, qk);
     LH_STAMP(22);
   }
   if constexpr (MODE == 2 && L >= TWL_MIN_L) {
@@ -731,59 +837,60 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   }
   if constexpr (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_in((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk.q);
+    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk);
   }
   if constexpr (MODE == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, canon_fwd<APPROX>(v[e], qk));
+    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, (u64)canon_fwd<AR>(v[e], qk));
     LH_STAMP(21);
   } else {
     LH_STAMP(23);
-    inv_transform<APPROX, L, LIO>(v, lds, tw, tau, qk);
+    inv_transform<AR, L, LIO>(v, lds, tw, tau, qk);
     LH_STAMP(24);
 #pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)lay_tab<LIO>.xr[e] * uT8, canon_inv<APPROX>(v[e], qk));
+    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)lay_tab<LIO>.xr[e] * uT8, (u64)canon_inv<AR>(v[e], qk));
     LH_STAMP(25);
   }
 }
 
-template <int L, int MODE, bool APPROX>
+template <int L, int MODE, int AR>
 static hipError_t launch_pow2_L(const Pow2Launch& a) {
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);
   constexpr int PPW = NT >= 256 ? 1 : 256 / NT;
   constexpr int LDSW = n + n / 16 + twl_words(n);
-  const size_t lds_bytes = (size_t)PPW * LDSW * sizeof(u64);
+  const size_t lds_bytes = (size_t)PPW * LDSW * sizeof(VT<AR>);
   const i64 items = a.B * a.T;
   const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
   const i64 grid = (items + PPW - 1) / PPW;
   if (grid == 0) return hipSuccess;
   static bool attr_set = false;
   if (!attr_set && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, APPROX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_pow2<L, MODE, APPROX>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
-                     a.y, a.a, a.b, a.B, a.T, a.tw_fwd, a.tw_inv, a.scale, a.mod, xcd_map);
+  hipLaunchKernelGGL((k_pow2<L, MODE, AR>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
+                     a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
+                     static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
   return hipGetLastError();
 }
 
-template <int MODE, bool APPROX>
+template <int MODE, int AR>
 static hipError_t launch_pow2_mode(const Pow2Launch& a) {
   switch (a.L) {
-    case 4: return launch_pow2_L<4, MODE, APPROX>(a);
-    case 5: return launch_pow2_L<5, MODE, APPROX>(a);
-    case 6: return launch_pow2_L<6, MODE, APPROX>(a);
-    case 7: return launch_pow2_L<7, MODE, APPROX>(a);
-    case 8: return launch_pow2_L<8, MODE, APPROX>(a);
-    case 9: return launch_pow2_L<9, MODE, APPROX>(a);
-    case 10: return launch_pow2_L<10, MODE, APPROX>(a);
-    case 11: return launch_pow2_L<11, MODE, APPROX>(a);
-    case 12: return launch_pow2_L<12, MODE, APPROX>(a);
-    case 13: return launch_pow2_L<13, MODE, APPROX>(a);
-    case 14: return launch_pow2_L<14, MODE, APPROX>(a);
+    case 4: return launch_pow2_L<4, MODE, AR>(a);
+    case 5: return launch_pow2_L<5, MODE, AR>(a);
+    case 6: return launch_pow2_L<6, MODE, AR>(a);
+    case 7: return launch_pow2_L<7, MODE, AR>(a);
+    case 8: return launch_pow2_L<8, MODE, AR>(a);
+    case 9: return launch_pow2_L<9, MODE, AR>(a);
+    case 10: return launch_pow2_L<10, MODE, AR>(a);
+    case 11: return launch_pow2_L<11, MODE, AR>(a);
+    case 12: return launch_pow2_L<12, MODE, AR>(a);
+    case 13: return launch_pow2_L<13, MODE, AR>(a);
+    case 14: return launch_pow2_L<14, MODE, AR>(a);
     default: return hipErrorInvalidValue;
   }
 }
@@ -794,11 +901,20 @@ extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(un
 }
 #endif
 
-hipError_t launch_pow2(const Pow2Launch& a, int mode) {
+template <int AR>
+static hipError_t launch_pow2_ar(const Pow2Launch& a, int mode) {
   switch (mode) {
-    case 0: return a.approx ? launch_pow2_mode<0, true>(a) : launch_pow2_mode<0, false>(a);
-    case 1: return a.approx ? launch_pow2_mode<1, true>(a) : launch_pow2_mode<1, false>(a);
-    case 2: return a.approx ? launch_pow2_mode<2, true>(a) : launch_pow2_mode<2, false>(a);
+    case 0: return launch_pow2_mode<0, AR>(a);
+    case 1: return launch_pow2_mode<1, AR>(a);
+    case 2: return launch_pow2_mode<2, AR>(a);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_pow2(const Pow2Launch& a, int mode) {
+  switch (a.arith) {
+    case 0: return launch_pow2_ar<0>(a, mode);
+    case 1: return launch_pow2_ar<1>(a, mode);
+    case 2: return launch_pow2_ar<2>(a, mode);
     default: return hipErrorInvalidValue;
   }
 }

@@ -340,6 +340,24 @@ int plan_upload(Plan& P) {
     if ((rc = upload(&P.pow2.d_tw_fwd, fwd))) return rc;
     if ((rc = upload(&P.pow2.d_tw_inv, inv))) return rc;
     if ((rc = upload(&P.pow2.d_scale, sc))) return rc;
+    bool small = true;
+    for (u64 q : P.qs) if (q >= (1ull << 30)) small = false;
+    if (small) {   // 32-bit Shoup pairs: wp = floor(w * 2^32 / q)
+      std::vector<uint32_t> f32(fwd.size()), i32(inv.size()), s32(sc.size());
+      for (int t = 0; t < T; ++t) {
+        const u64 q = P.qs[(size_t)t];
+        for (i64 i = 0; i < n; ++i) {
+          const size_t o = ((size_t)t * n + (size_t)i) * 2;
+          f32[o] = (uint32_t)fwd[o]; f32[o + 1] = (uint32_t)((fwd[o] << 32) / q);
+          i32[o] = (uint32_t)inv[o]; i32[o + 1] = (uint32_t)((inv[o] << 32) / q);
+        }
+        s32[(size_t)t * 2] = (uint32_t)sc[(size_t)t * 2];
+        s32[(size_t)t * 2 + 1] = (uint32_t)((sc[(size_t)t * 2] << 32) / q);
+      }
+      if ((rc = upload(&P.pow2.d_tw_fwd32, f32))) return rc;
+      if ((rc = upload(&P.pow2.d_tw_inv32, i32))) return rc;
+      if ((rc = upload(&P.pow2.d_scale32, s32))) return rc;
+    }
   }
   // polynomials too large for the LDS ping-pong run the generic path out of HBM scratch
   if (2 * (size_t)P.n * sizeof(u64) > 152 * 1024) {
@@ -355,6 +373,7 @@ void plan_free_device(Plan& P) {
   fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_scratch); fr(P.d_tmp);
   P.d_tmp = nullptr; P.tmp_bytes = 0;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
+  fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
   P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr; P.d_scratch = nullptr;

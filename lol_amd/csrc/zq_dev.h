@@ -36,6 +36,7 @@ struct ModCtx {
   u64 v;   // floor((2^128-1)/d) - 2^64
   u32 s;   // normalisation shift (>= 2 because q < 2^62)
   u32 pad;
+  u64 mu;  // floor(2^64 / q) (Barrett constant of the 32-bit path)
 };
 
 // Shoup pair: w and floor(w * 2^64 / q)
@@ -49,6 +50,7 @@ inline ModCtx make_modctx(u64 q) {
   c.d = q << c.s;
   c.v = (u64)((~(unsigned __int128)0) / c.d - ((unsigned __int128)1 << 64));
   c.pad = 0;
+  c.mu = (u64)((((unsigned __int128)1) << 64) / q);
   return c;
 }
 inline ShoupW make_shoup(u64 w, u64 q) {
@@ -107,13 +109,25 @@ LH_D u64 shl1_add64(u64 a, u64 b) {
   asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// the same two with a WAVE-UNIFORM addend read straight from an SGPR pair (the per-modulus
+// constants): one VGPR pair less per constant in a kernel that sits at the register limit
+LH_D u64 add64u(u64 a, u64 b_uniform) {
+  u64 d;
+  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
+  return d;
+}
+LH_D u64 shl1_add64u(u64 a, u64 b_uniform) {
+  u64 d;
+  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
+  return d;
+}
 LH_D u32 lo32(u64 x) { return (u32)x; }
 LH_D u32 hi32(u64 x) { return (u32)(x >> 32); }
 
 // x + negm if that is non-negative else x, i.e. csub(x, m) with negm = -m (mod 2^64);
 // requires |x - m| < 2^63
 LH_D u64 csubn(u64 x, u64 negm) {
-  u64 t = add64(x, negm);
+  u64 t = add64u(x, negm);     // negm is a per-modulus constant everywhere this is used
   return ((int)hi32(t) < 0) ? x : t;
 }
 
@@ -143,7 +157,7 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
       "v_mad_u64_u32 %1, vcc, %7, %8, %1"
       : "=&v"(t), "=&v"(h)
       : "v"(lo32(w)), "v"(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),
-        "v"(lo32(nq)), "v"(hi32(nq)), "v"(init)
+        "s"(lo32(nq)), "s"(hi32(nq)), "v"(init)      // nq: wave-uniform, one SGPR operand per mad
       : "vcc");
   u32 th;
   asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));

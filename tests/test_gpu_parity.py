@@ -306,6 +306,41 @@ def test_extreme_values_and_moduli(gpu, cpuref):
         gpu.Plan([(2, 4)], [2 ** 62 + 1])
 
 
+@pytest.mark.parametrize("m", [2 ** 5, 2 ** 10, 2 ** 12, 2 ** 14])
+def test_arithmetic_class_boundaries(gpu, cpuref, m):
+    """The m = 2^k path picks its arithmetic per plan: 32-bit residues when every modulus is
+    below 2^30, 64-bit lazy Shoup below 2^61, exact above.  Moduli hugging each boundary, the
+    extreme residues, and tuples that mix classes (the widest class must win)."""
+    pps = lm.factor_pps(m)
+
+    def last_good_below(bound):
+        q = (bound - 2) // m * m + 1
+        while not lm.is_prime(q):
+            q -= m
+        return q
+
+    q_lo = last_good_below(2 ** 30)            # largest 32-bit-class modulus
+    q_mid = lm.first_good_q(m, 2 ** 30)        # smallest 64-bit-class modulus
+    q_hi = last_good_below(2 ** 61)            # largest lazy-class modulus
+    q_top = lm.first_good_q(m, 2 ** 61)        # smallest exact-class modulus
+    assert q_lo < 2 ** 30 < q_mid and q_hi < 2 ** 61 < q_top
+    rng = np.random.default_rng(m)
+    for qs in ([q_lo], [q_mid], [q_hi], [q_top], [q_lo, 12289 if m <= 4096 else 65537],
+               [q_lo, q_mid], [q_mid, q_hi, q_lo], [q_top, q_lo]):
+        P, R = gpu.Plan(pps, qs), Params(pps, qs)
+        y, z = R.random(rng, 3), R.random(rng, 3)
+        for t, q in enumerate(qs):                 # extreme residues in two of the polynomials
+            y[0, :, t] = q - 1
+            z[1, :, t] = q - 1
+        y[2, ::2] = 0
+        assert np.array_equal(P.crt(y), cpuref.crt(R, y)), qs
+        assert np.array_equal(P.crtInv(y), cpuref.crtinv(R, y)), qs
+        assert np.array_equal(P.polymul(y, z), cpuref.polymul(R, y, z)), qs
+        assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y)), qs
+        neg = np.where(y > 0, y - np.asarray(qs, dtype=np.int64), 0)   # representatives in (-q, 0]
+        assert np.array_equal(P.crt(neg), cpuref.crt(R, y)), qs
+
+
 def test_divg_failure_is_reported(gpu):
     """oddRad(m) not invertible mod q -> Nothing in the reference (g.cpp:194-199, CPP.hs:321-323)"""
     P = gpu.Plan([(3, 1), (7, 1)], [21])
