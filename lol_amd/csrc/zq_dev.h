@@ -136,7 +136,36 @@ LH_D u64 csubn(u64 x, u64 negm) {
 // so (result - init) = w*y mod q + {0..3}*q  in [0, 4q) for any 64-bit y.  7 mads + 2
 // mul_hi instead of the 10 multiplies of the exact form; nq = -q (mod 2^64).
 LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
-#if LOLHIP_ASM_MAD == 3
+#if LOLHIP_ASM_MAD == 4
+  // One block, 9 v_mad_u64_u32.  The quotient's cross terms are summed EXACTLY:
+  //   C = wp.hi*y.lo + wp.lo*y.hi  (65 bits: 64 in v[120:121], the carry in vcc)
+  //   Q = wp.hi*y.hi + (C >> 32)   in {floor(wp*y/2^64) - 1, same}
+  // and C >> 32 is assembled as the pair v[122:123] = {C.hi, carry} (VGPR pairs must be
+  // even-aligned, so it cannot simply overlap C).  Halves of a 64-bit asm operand cannot be
+  // named, hence the six hard-wired scratch VGPRs (every kernel using this has a 128-VGPR
+  // budget).  gfx950 needs 2 wait states between a VALU
+  // write of vcc and a VALU read of it; three independent mads sit in between, their junk
+  // carries go to another SGPR pair.
+  u64 t = init, h, sj;
+  asm("v_mad_u64_u32 v[120:121], vcc, %[wph], %[ylo], 0\n\t"
+      "v_mad_u64_u32 v[120:121], vcc, %[wpl], %[yhi], v[120:121]\n\t"
+      "v_mad_u64_u32 %[t], %[sj], %[wl], %[ylo], %[t]\n\t"
+      "v_mad_u64_u32 %[h], %[sj], %[wl], %[yhi], 0\n\t"
+      "v_mad_u64_u32 %[h], %[sj], %[wh], %[ylo], %[h]\n\t"
+      "v_mov_b32 v122, v121\n\t"
+      "v_cndmask_b32_e64 v123, 0, 1, vcc\n\t"
+      "v_mad_u64_u32 v[118:119], %[sj], %[wph], %[yhi], v[122:123]\n\t"
+      "v_mad_u64_u32 %[t], %[sj], v118, %[nql], %[t]\n\t"
+      "v_mad_u64_u32 %[h], %[sj], v118, %[nqh], %[h]\n\t"
+      "v_mad_u64_u32 %[h], %[sj], v119, %[nql], %[h]"
+      : [t] "+v"(t), [h] "=&v"(h), [sj] "=&s"(sj)
+      : [wph] "v"(hi32(wp)), [wpl] "v"(lo32(wp)), [ylo] "v"(lo32(y)), [yhi] "v"(hi32(y)),
+        [wl] "v"(lo32(w)), [wh] "v"(hi32(w)), [nql] "s"(lo32(nq)), [nqh] "s"(hi32(nq))
+      : "vcc", "v118", "v119", "v120", "v121", "v122", "v123");
+  u32 th;
+  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  return ((u64)th << 32) | lo32(t);
+#elif LOLHIP_ASM_MAD == 3
   // Two asm blocks per product (hipcc pads every separate asm statement that writes an SGPR
   // carry with s_nop; inside a block there is nothing to pad: VGPR RAW is interlocked).
   u64 Q, t, h;
