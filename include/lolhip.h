@@ -146,6 +146,56 @@ LOLHIP_API int lolhip_embed_crt_batch   (const lolhip_ext *x, void *stream, int6
  * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468) */
 LOLHIP_API int64_t lolhip_ext_table(const lolhip_ext *x, int which, int32_t *out, int64_t len);
 
+/* --- ring-level pipelines of SymmSHE, device pointers -----------
+ * In the reference these are Haskell compositions of the Tensor methods above on one
+ * ring element at a time; here each is one or two passes over a batch slab.  All slabs
+ * are [.][B][n][T] int64, component t innermost.  Up to 16 RNS components.              */
+
+/* Coefficients of  mulG <$> (c * d)  for two linear ciphertexts c = c0 + c1 s,
+ * d = d0 + d1 s, every operand in the CRT basis (lol-apps SymmSHE.hs:444-449; mulG in the
+ * CRT basis is the pointwise product with gCRT, CPP.hs:230):
+ *   e0 = g c0 d0,  e1 = g (c0 d1 + c1 d0),  e2 = g c1 d1.
+ * One pass: 4 reads, 3 writes.  Outputs may alias inputs. */
+LOLHIP_API int lolhip_ctmul_crt_batch(const lolhip_plan *p, void *stream, const int64_t *c0, const int64_t *c1,
+                                      const int64_t *d0, const int64_t *d1, int64_t *e0, int64_t *e1,
+                                      int64_t *e2, int64_t B);
+
+/* Gadget decomposition (Decompose gad (Cyc t m zq), Cyc.hs:592-604): base 0 = TrivGad
+ * (ZqBasic.hs:227-232: one digit per component, its centred lift), base b >= 2 = BaseBGad b
+ * (ZqBasic.hs:258-264: gadlen(b, q_t) centred base-b digits, Numeric.hs:202-205,227-234);
+ * product rings concatenate, first component first (Gadget.hs:96-101).
+ * lolhip_decompose_len: number of digits L (negative status on error).
+ * lolhip_gadget: the gadget vector as [L][T] residues (b^k in its own component, zero
+ *   elsewhere; Gadget.hs:92-94), host array of at least L*T entries; returns L.
+ * lolhip_decompose_batch: c in the powerful basis [B][n][T] -> digits [L][B][n][T], every
+ *   integer digit polynomial already reduced into all T components (`fmap reduce`,
+ *   SymmSHE.hs:314). */
+LOLHIP_API int lolhip_decompose_len(const lolhip_plan *p, int64_t base);
+LOLHIP_API int lolhip_gadget(const lolhip_plan *p, int64_t base, int64_t *out, int64_t cap);
+LOLHIP_API int lolhip_decompose_batch(const lolhip_plan *p, void *stream, const int64_t *c_pow, int64_t base,
+                                      int64_t *digits, int64_t B);
+
+/* knapsack (SymmSHE.hs:302-304): out_k = addend_k + sum_j xs_j * hint_jk, CRT basis.
+ * xs [L][B][n][T]; hint [L][K][n][T], shared by the whole batch (K = 1..3 coefficients
+ * of the hint polynomials); addend [K][B][n][T] or NULL; out [K][B][n][T] (may alias addend). */
+LOLHIP_API int lolhip_knapsack_batch(const lolhip_plan *p, void *stream, const int64_t *xs_crt, int L,
+                                     const int64_t *hint, int K, const int64_t *addend, int64_t *out, int64_t B);
+
+/* `switch` (SymmSHE.hs:312-314) and with it keySwitchQuadCirc (:361-371, addend = the CRT
+ * forms of c0, c1):  out = addend + knapsack hint (crt (reduce <$> decompose c2)).
+ * c2 in the powerful basis [B][n][T]; work: caller-provided device scratch of
+ * lolhip_decompose_len * B * n * T int64 (it holds the digit polynomials). */
+LOLHIP_API int lolhip_keyswitch_batch(const lolhip_plan *p, void *stream, const int64_t *c2_pow, int64_t base,
+                                      const int64_t *hint, int K, const int64_t *addend, int64_t *out,
+                                      int64_t *work, int64_t B);
+
+/* RescaleCyc (a,b) -> b (Cyc.hs:529-542): drop the first modulus of the tuple.  With
+ * z = lift a coefficient-wise (powerful or decoding basis),
+ *   out_s = q_0^-1 (c_s - z)  mod q_s   for s = 1..T-1.
+ * c [B][n][T] -> out [B][n][T-1].  LOLHIP_ERR_MODULUS if q_0 is not invertible mod some q_s. */
+LOLHIP_API int lolhip_rescale_drop_batch(const lolhip_plan *p, void *stream, const int64_t *c, int64_t *out,
+                                         int64_t B);
+
 /* --- host-pointer convenience (H2D, run, D2H on an internal stream) --------------
  * op: see LOLHIP_OP_*.  y (and b for MUL/POLYMUL) are host arrays of B polynomials. */
 enum {

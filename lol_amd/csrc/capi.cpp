@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "pipeline.h"
 #include "lolhip.h"
 #include "plan.h"
 
@@ -233,6 +234,119 @@ int lolhip_divgcrt_batch(const lolhip_plan* p, void* stream, int64_t* y, int64_t
   const i64 per = p->P.n * p->P.T;
   return launch_pointwise_mul((hipStream_t)stream, y, p->P.d_ginvcrt, B * per, per, p->P.T, p->P.d_mod) == hipSuccess
              ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
+// ---- ring-level pipelines ---------------------------------------------
+
+namespace {
+
+int gadlen(u64 b, u64 q) {   // ZqBasic.hs:238-240: base-b digits of q
+  int k = 0;
+  while (q != 0) { ++k; q /= b; }
+  return k;
+}
+
+// digit counts and the invariant-divisor constants for `base` over the plan's moduli
+int make_decomp(const Plan& P, int64_t base, DecompParams& d) {
+  if (P.T > PIPE_MAX_T) return LOLHIP_ERR_INVALID;
+  if (base != 0 && base < 2) return LOLHIP_ERR_INVALID;
+  d.T = P.T;
+  d.base = base;
+  d.L = 0;
+  for (int t = 0; t < P.T; ++t) {
+    d.k[t] = base == 0 ? 1 : gadlen((u64)base, P.qs[t]);
+    d.L += d.k[t];
+  }
+  d.magic = 1; d.sh1 = 0; d.sh2 = 0;
+  if (base >= 2) {
+    int l = 0;
+    while (((u128)1 << l) < (u128)base) ++l;                       // ceil(log2 base)
+    d.magic = (u64)((((u128)1 << 64) * (((u128)1 << l) - (u128)base)) / (u128)base) + 1;
+    d.sh1 = l < 1 ? l : 1;
+    d.sh2 = l > 1 ? l - 1 : 0;
+  }
+  return LOLHIP_OK;
+}
+
+}  // namespace
+
+int lolhip_ctmul_crt_batch(const lolhip_plan* p, void* stream, const int64_t* c0, const int64_t* c1,
+                           const int64_t* d0, const int64_t* d1, int64_t* e0, int64_t* e1, int64_t* e2, int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  if (!p->P.has_crt) return LOLHIP_ERR_NO_CRT;
+  if (B < 0 || (B > 0 && (!c0 || !c1 || !d0 || !d1 || !e0 || !e1 || !e2))) return LOLHIP_ERR_INVALID;
+  return launch_ctmul((hipStream_t)stream, c0, c1, d0, d1, e0, e1, e2, p->P.d_gcrt, B, p->P.n, p->P.T, p->P.d_mod)
+                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
+int lolhip_decompose_len(const lolhip_plan* p, int64_t base) {
+  if (!p) return LOLHIP_ERR_INVALID;
+  DecompParams d;
+  int rc = make_decomp(p->P, base, d);
+  return rc ? rc : d.L;
+}
+
+int lolhip_gadget(const lolhip_plan* p, int64_t base, int64_t* out, int64_t cap) {
+  if (!p || !out) return LOLHIP_ERR_INVALID;
+  DecompParams d;
+  int rc = make_decomp(p->P, base, d); if (rc) return rc;
+  const int T = p->P.T;
+  if (cap < (int64_t)d.L * T) return LOLHIP_ERR_INVALID;
+  int j = 0;
+  for (int t = 0; t < T; ++t)
+    for (int k = 0; k < d.k[t]; ++k, ++j)
+      for (int s = 0; s < T; ++s)
+        out[(int64_t)j * T + s] = s != t ? 0 : (base == 0 ? 1 % (int64_t)p->P.qs[t] : (int64_t)powmod((u64)base % p->P.qs[t], (u64)k, p->P.qs[t]));
+  return d.L;
+}
+
+int lolhip_decompose_batch(const lolhip_plan* p, void* stream, const int64_t* c_pow, int64_t base, int64_t* digits,
+                           int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  DecompParams d;
+  rc = make_decomp(p->P, base, d); if (rc) return rc;
+  if (B < 0 || (B > 0 && (!c_pow || !digits))) return LOLHIP_ERR_INVALID;
+  return launch_decompose((hipStream_t)stream, c_pow, digits, B, p->P.n, d, p->P.d_mod) == hipSuccess
+             ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
+int lolhip_knapsack_batch(const lolhip_plan* p, void* stream, const int64_t* xs_crt, int L, const int64_t* hint,
+                          int K, const int64_t* addend, int64_t* out, int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  if (L < 0 || K < 1 || K > 3 || B < 0) return LOLHIP_ERR_INVALID;
+  if (B > 0 && (!out || (L > 0 && (!xs_crt || !hint)))) return LOLHIP_ERR_INVALID;
+  return launch_knapsack((hipStream_t)stream, xs_crt, L, hint, K, addend, out, B, p->P.n, p->P.T, p->P.d_mod)
+                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
+int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2_pow, int64_t base,
+                           const int64_t* hint, int K, const int64_t* addend, int64_t* out, int64_t* work, int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  if (!p->P.has_crt) return LOLHIP_ERR_NO_CRT;
+  DecompParams d;
+  rc = make_decomp(p->P, base, d); if (rc) return rc;
+  if (K < 1 || K > 3 || B < 0 || (B > 0 && (!c2_pow || !hint || !out || !work))) return LOLHIP_ERR_INVALID;
+  if (B == 0) return LOLHIP_OK;
+  if (launch_decompose((hipStream_t)stream, c2_pow, work, B, p->P.n, d, p->P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
+  rc = lolhip_crt_batch(p, stream, work, (int64_t)d.L * B);          // all L*B digit polynomials in one launch
+  if (rc) return rc;
+  return launch_knapsack((hipStream_t)stream, work, d.L, hint, K, addend, out, B, p->P.n, p->P.T, p->P.d_mod)
+                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
+int lolhip_rescale_drop_batch(const lolhip_plan* p, void* stream, const int64_t* c, int64_t* out, int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  const Plan& P = p->P;
+  if (P.T < 2 || P.T > PIPE_MAX_T) return LOLHIP_ERR_INVALID;
+  if (B < 0 || (B > 0 && (!c || !out))) return LOLHIP_ERR_INVALID;
+  RescaleParams r;
+  r.T = P.T;
+  r.qa_inv[0] = 0;
+  for (int s = 1; s < P.T; ++s) {
+    r.qa_inv[s] = invmod(P.qs[0] % P.qs[s], P.qs[s]);
+    if (r.qa_inv[s] == 0) return LOLHIP_ERR_MODULUS;
+  }
+  return launch_rescale((hipStream_t)stream, c, out, B, P.n, r, P.d_mod) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
 // ---- ring extensions -----------------------------------------------------------------

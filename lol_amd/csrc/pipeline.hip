@@ -1,0 +1,195 @@
+// lol_amd/csrc/pipeline.hip — fused streaming kernels for the ring-level pipelines SymmSHE
+// builds out of Tensor ops.  gfx950 only; all four are HBM-bound
+// element-wise passes over [.][B][n][T] int64 slabs (component t innermost).
+//
+//   k_ctmul      mulG <$> (c * d) for two linear ciphertexts, CRT basis   SymmSHE.hs:444-449
+//   k_decompose  gadget decomposition of powerful-basis coefficients, every integer digit
+//                reduced into all T components                            Cyc.hs:592-604,
+//                Gadget.hs:96-101, ZqBasic.hs:227-264, Numeric.hs:202-205,227-234, SymmSHE.hs:314
+//   k_knapsack   sum_j x_j *>> hint_j (+ addend), CRT basis               SymmSHE.hs:302-304,365-371
+//   k_rescale    RescaleCyc (a,b) -> b: q_a^-1 (b - reduce (lift a))      Cyc.hs:529-542
+//
+// What the reference does op by op on boxed Haskell vectors (4 ring products, an addition and
+// three mulG for a ciphertext product: 21 slab passes) is one pass here (4 reads, 3 writes).
+#include <hip/hip_runtime.h>
+
+#include "pipeline.h"
+#include "zq_dev.h"
+
+namespace lolhip {
+
+typedef unsigned __int128 u128;
+
+static inline unsigned grid_for(i64 total) {
+  i64 blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+// ---------------------------------------------------------------------------------------
+// ct x ct
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_ctmul(const i64* c0, const i64* c1, const i64* d0, const i64* d1, i64* e0, i64* e1, i64* e2,
+        const i64* __restrict__ gcrt, i64 total, u32 per, int T, const ModCtx* __restrict__ mod) {
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const u32 r = (u32)(g % per);
+    const ModCtx mc = mod[r % (u32)T];
+    const u64 gv = (u64)gcrt[r];
+    const u64 a0 = canon_in(c0[g], mc.q), a1 = canon_in(c1[g], mc.q);
+    const u64 b0 = canon_in(d0[g], mc.q), b1 = canon_in(d1[g], mc.q);
+    const u64 p0 = mulmod(a0, b0, mc);
+    const u64 p2 = mulmod(a1, b1, mc);
+    const u128 cross = (u128)a0 * b1 + (u128)a1 * b0;          // < 2 q^2 < q * 2^64
+    const u64 p1 = rem128((u64)(cross >> 64), (u64)cross, mc);
+    // all four inputs are read: the outputs may alias them
+    e0[g] = (i64)mulmod(gv, p0, mc);
+    e1[g] = (i64)mulmod(gv, p1, mc);
+    e2[g] = (i64)mulmod(gv, p2, mc);
+  }
+}
+
+hipError_t launch_ctmul(hipStream_t s, const i64* c0, const i64* c1, const i64* d0, const i64* d1, i64* e0, i64* e1,
+                        i64* e2, const i64* gcrt, i64 B, i64 n, int T, const ModCtx* mod) {
+  const i64 total = B * n * T;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ctmul, dim3(grid_for(total)), dim3(256), 0, s, c0, c1, d0, d1, e0, e1, e2, gcrt, total,
+                     (u32)(n * T), T, mod);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// decompose
+// ---------------------------------------------------------------------------------------
+// floor(x / base) for any signed x, base >= 2, through the invariant-divisor multiply
+__device__ __forceinline__ i64 floor_div(i64 x, const DecompParams& p) {
+  const u64 n = x >= 0 ? (u64)x : (u64)(-x - 1);
+  const u64 t1 = __umul64hi(p.magic, n);
+  const u64 q = (t1 + ((n - t1) >> p.sh1)) >> p.sh2;
+  return x >= 0 ? (i64)q : -(i64)q - 1;
+}
+
+// residue of a signed integer (|d| < 2^63) modulo q
+__device__ __forceinline__ u64 reduce_signed(i64 d, const ModCtx& mc) {
+  const u64 a = d >= 0 ? (u64)d : (u64)(-d);
+  const u64 r = rem128(0, a, mc);
+  return (d < 0 && r != 0) ? mc.q - r : r;
+}
+
+__global__ void __launch_bounds__(256)
+k_decompose(const i64* __restrict__ c, i64* __restrict__ digits, i64 rows, DecompParams p,
+            const ModCtx* __restrict__ mod) {
+  const int T = p.T;
+  const i64 total = rows * T;              // one thread per output column (row r, component s)
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  const i64 shift = p.base / 2;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const i64 r = g / T;
+    const int s = (int)(g - r * T);
+    const ModCtx ms = mod[s];
+    i64 j = 0;
+    for (int t = 0; t < T; ++t) {
+      const u64 qt = mod[t].q;
+      const u64 x = canon_in(c[r * T + t], qt);
+      i64 v = (2 * x < qt) ? (i64)x : (i64)x - (i64)qt;          // lift: [-q/2, q/2)
+      for (int k = 0; k + 1 < p.k[t]; ++k, ++j) {                 // centred base-b digits
+        const i64 a = v + shift;
+        const i64 qd = floor_div(a, p);
+        const i64 rem = a - qd * p.base - shift;
+        v = qd;
+        digits[(j * rows + r) * T + s] = (i64)reduce_signed(rem, ms);
+      }
+      digits[(j * rows + r) * T + s] = (i64)reduce_signed(v, ms);  // last digit: what is left
+      ++j;
+    }
+  }
+}
+
+hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64 n, const DecompParams& p,
+                            const ModCtx* mod) {
+  const i64 rows = B * n;
+  if (rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_decompose, dim3(grid_for(rows * p.T)), dim3(256), 0, s, c, digits, rows, p, mod);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// knapsack
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256)
+k_knapsack(const i64* __restrict__ xs, int L, const i64* __restrict__ hint, const i64* addend, i64* out, i64 total,
+           u32 per, int T, const ModCtx* __restrict__ mod) {
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const u32 r = (u32)(g % per);
+    const ModCtx mc = mod[r % (u32)T];
+    u128 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0;
+    for (int j = 0; j < L; ++j) {
+      const u64 x = canon_in(xs[(i64)j * total + g], mc.q);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const u64 h = canon_in(hint[((i64)j * K + k) * per + r], mc.q);
+        acc[k] += (u128)x * h;                                   // each term < q^2 < 2^124
+      }
+      if ((j & 7) == 7) {                                        // keep the sum below 2^128
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = reduce128((u64)(acc[k] >> 64), (u64)acc[k], mc);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u64 v = reduce128((u64)(acc[k] >> 64), (u64)acc[k], mc);
+      if (addend) v = addmod(v, canon_in(addend[(i64)k * total + g], mc.q), mc.q);
+      out[(i64)k * total + g] = (i64)v;
+    }
+  }
+}
+
+hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint, int K, const i64* addend, i64* out,
+                           i64 B, i64 n, int T, const ModCtx* mod) {
+  const i64 total = B * n * T;
+  if (total == 0) return hipSuccess;
+  const dim3 grid(grid_for(total)), block(256);
+  const u32 per = (u32)(n * T);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(k_knapsack<1>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
+    case 2: hipLaunchKernelGGL(k_knapsack<2>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
+    case 3: hipLaunchKernelGGL(k_knapsack<3>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// rescale: drop component 0
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rescale(const i64* __restrict__ c, i64* __restrict__ out, i64 rows, RescaleParams p, const ModCtx* __restrict__ mod) {
+  const int To = p.T - 1;
+  const i64 total = rows * To;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  const u64 qa = mod[0].q;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const i64 r = g / To;
+    const int s = (int)(g - r * To) + 1;
+    const ModCtx ms = mod[s];
+    const u64 a = canon_in(c[r * p.T], qa);
+    const i64 z = (2 * a < qa) ? (i64)a : (i64)a - (i64)qa;      // lift a
+    const u64 b = canon_in(c[r * p.T + s], ms.q);
+    out[g] = (i64)mulmod(submod(b, reduce_signed(z, ms), ms.q), p.qa_inv[s], ms);
+  }
+}
+
+hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, const RescaleParams& p,
+                          const ModCtx* mod) {
+  const i64 rows = B * n;
+  if (rows == 0 || p.T < 2) return hipSuccess;
+  hipLaunchKernelGGL(k_rescale, dim3(grid_for(rows * (p.T - 1))), dim3(256), 0, s, c, out, rows, p, mod);
+  return hipGetLastError();
+}
+
+}  // namespace lolhip

@@ -93,6 +93,13 @@ def lib():
         getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, i64]
     L.lolhip_mul_batch.argtypes = [vp, vp, vp, vp, i64]
     L.lolhip_polymul_batch.argtypes = [vp, vp, vp, vp, vp, i64]
+    L.lolhip_ctmul_crt_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
+    L.lolhip_decompose_len.argtypes = [vp, i64]
+    L.lolhip_gadget.argtypes = [vp, i64, _i64p, i64]
+    L.lolhip_decompose_batch.argtypes = [vp, vp, vp, i64, vp, i64]
+    L.lolhip_knapsack_batch.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, i64]
+    L.lolhip_keyswitch_batch.argtypes = [vp, vp, vp, i64, vp, ci, vp, vp, vp, i64]
+    L.lolhip_rescale_drop_batch.argtypes = [vp, vp, vp, vp, i64]
     L.lolhip_ext_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.lolhip_ext_destroy.argtypes = [vp]
     L.lolhip_ext_destroy.restype = None
@@ -289,6 +296,84 @@ class Plan:
         out = a if out is None else out
         _check(lib().lolhip_polymul_batch(self._h, _stream(stream), _devptr(out), _devptr(a), _devptr(b), self._batch_t(a)))
         return out
+
+
+    # ---- ring-level pipelines of SymmSHE (include/lolhip.h) -----------
+    # numpy in -> numpy out (staged through HBM with torch); CUDA tensors in -> CUDA tensors out.
+    @staticmethod
+    def _stage(*arrays):
+        import torch
+        host = isinstance(arrays[0], np.ndarray)
+        dev = [None if a is None else (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).cuda() if host else a)
+               for a in arrays]
+        return host, dev
+
+    @staticmethod
+    def _unstage(host, *tensors):
+        out = tuple(t.cpu().numpy() if host else t for t in tensors)
+        return out if len(out) > 1 else out[0]
+
+    def ctMulCRT(self, c0, c1, d0, d1, stream=None):
+        """(g c0 d0, g (c0 d1 + c1 d0), g c1 d1): mulG <$> c*d for two linear ciphertexts, every
+        operand in the CRT basis (SymmSHE.hs:444-449)."""
+        import torch
+        host, (c0, c1, d0, d1) = self._stage(c0, c1, d0, d1)
+        e = [torch.empty_like(c0) for _ in range(3)]
+        _check(lib().lolhip_ctmul_crt_batch(self._h, _stream(stream), *map(_devptr, (c0, c1, d0, d1, *e)), self._batch_t(c0)))
+        return self._unstage(host, *e)
+
+    def decomposeLen(self, base):
+        L = lib().lolhip_decompose_len(self._h, int(base))
+        _check(min(L, 0))
+        return L
+
+    def gadget(self, base):
+        """gadget vector [L][T] (Gadget.hs:92-94 over ZqBasic.hs:227-229,248-253)."""
+        L = self.decomposeLen(base)
+        out = np.zeros((L, self.T), dtype=np.int64)
+        _check(min(lib().lolhip_gadget(self._h, int(base), out.ctypes.data_as(_i64p), out.size), 0))
+        return out
+
+    def decompose(self, c, base, stream=None):
+        """powerful-basis c [B][n][T] -> reduced digit polynomials [L][B][n][T] (Cyc.hs:592-604)."""
+        import torch
+        host, (c,) = self._stage(c)
+        B, L = self._batch_t(c), self.decomposeLen(base)
+        out = torch.empty((L, B, self.n, self.T), dtype=torch.int64, device=c.device)
+        _check(lib().lolhip_decompose_batch(self._h, _stream(stream), _devptr(c), int(base), _devptr(out), B))
+        return self._unstage(host, out)
+
+    def knapsack(self, xs_crt, hint, addend=None, stream=None):
+        """sum_j xs_j *>> hint_j (+ addend), CRT basis (SymmSHE.hs:302-304): xs [L][B][n][T],
+        hint [L][K][n][T] -> [K][B][n][T]."""
+        import torch
+        host, (xs_crt, hint, addend) = self._stage(xs_crt, hint, addend)
+        L, K = xs_crt.shape[0], hint.shape[1]
+        B = self._batch_t(xs_crt) // max(L, 1)
+        out = torch.empty((K, B, self.n, self.T), dtype=torch.int64, device=hint.device)
+        _check(lib().lolhip_knapsack_batch(self._h, _stream(stream), _devptr(xs_crt), L, _devptr(hint), K,
+                                           None if addend is None else _devptr(addend), _devptr(out), B))
+        return self._unstage(host, out)
+
+    def keySwitch(self, c2_pow, base, hint, addend=None, stream=None):
+        """addend + knapsack hint (crt (reduce <$> decompose c2)) — `switch`, SymmSHE.hs:312-314."""
+        import torch
+        host, (c2_pow, hint, addend) = self._stage(c2_pow, hint, addend)
+        B, L, K = self._batch_t(c2_pow), self.decomposeLen(base), hint.shape[1]
+        work = torch.empty((L, B, self.n, self.T), dtype=torch.int64, device=c2_pow.device)
+        out = torch.empty((K, B, self.n, self.T), dtype=torch.int64, device=c2_pow.device)
+        _check(lib().lolhip_keyswitch_batch(self._h, _stream(stream), _devptr(c2_pow), int(base), _devptr(hint), K,
+                                            None if addend is None else _devptr(addend), _devptr(out), _devptr(work), B))
+        return self._unstage(host, out)
+
+    def rescaleDropFirst(self, c, stream=None):
+        """RescaleCyc (a,b) -> b (Cyc.hs:529-542): [B][n][T] -> [B][n][T-1]."""
+        import torch
+        host, (c,) = self._stage(c)
+        B = self._batch_t(c)
+        out = torch.empty((B, self.n, self.T - 1), dtype=torch.int64, device=c.device)
+        _check(lib().lolhip_rescale_drop_batch(self._h, _stream(stream), _devptr(c), _devptr(out), B))
+        return self._unstage(host, out)
 
 
 class Ext:
