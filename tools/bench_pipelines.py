@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""tools/bench_pipelines.py — throughput of the SymmSHE pipeline kernels on one MI355X
+(BASELINE configs 3 and 5 shapes).  Operands resident in HBM, HIP events on
+the launch stream.  Prints one JSON object per line; `alg_bytes` is the compulsory traffic
+of the *fused ideal* (each input slab read once, each output written once)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lol_amd  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    return sum(s.elapsed_time(e) for s, e in ev) / iters
+
+
+def rnd(gen, qs, *shape):
+    return torch.stack([torch.randint(0, q, shape, dtype=torch.int64, device="cuda", generator=gen) for q in qs], dim=-1)
+
+
+def report(name, cfg, ms, items, alg_bytes):
+    print(json.dumps({"op": name, "config": cfg, "ms": round(ms, 4), "items_per_s": round(items / ms * 1e3, 1),
+                      "alg_GBps": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000, 4)}), flush=True)
+
+
+def good_qs(m, lower, T):
+    out, lo = [], lower
+    for _ in range(T):
+        q = lol_amd.good_q(m, lo)
+        out.append(q); lo = q
+    return out
+
+
+def main():
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    L = lol_amd.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    # ---- config 3: ciphertext product, m = 2^15, T = 4, ~59-bit moduli ------------------
+    qs = good_qs(2 ** 15, 2 ** 59, 4)
+    P = lol_amd.Plan([(2, 15)], qs)
+    B = 256
+    ops = [rnd(gen, qs, B, P.n) for _ in range(4)]
+    outs = [torch.empty_like(ops[0]) for _ in range(3)]
+    slab = B * P.n * P.T * 8
+    ptr = lambda t: t.data_ptr()
+    ms = timeit(lambda: L.lolhip_ctmul_crt_batch(P._h, st, *map(ptr, ops + outs), B))
+    report("ctmul_crt", f"m=2^15 T=4 59-bit B={B}", ms, B, 7 * slab)
+    # the same product op by op (what a Tensor-method-at-a-time backend does): 4 mul, 1 add, 3 mulGCRT
+    def unfused():
+        a, b_, c_, d_ = (o.clone() for o in (ops[0], ops[0], ops[1], ops[1]))
+        P.mul(a, ops[2]); P.mul(b_, ops[3]); P.mul(c_, ops[2]); P.mul(d_, ops[3])
+        b_ += c_
+        P.mulGCRT(a); P.mulGCRT(b_); P.mulGCRT(d_)
+    ms_u = timeit(unfused, iters=5)
+    report("ctmul_crt_op_by_op", f"m=2^15 T=4 59-bit B={B}", ms_u, B, 7 * slab)
+    del ops, outs
+    # ---- config 5: key switch, m' = 2048, q = (1017857, 1032193), TrivGad; and at n = 8192 -----
+    for lm_, qs5, B in ((11, [1017857, 1032193], 8192), (14, good_qs(2 ** 14, 2 ** 20, 2), 1024)):
+        P = lol_amd.Plan([(2, lm_)], qs5)
+        for base in (0, 256):
+            Ld = P.decomposeLen(base)
+            c2 = rnd(gen, qs5, B, P.n)
+            add = torch.stack([rnd(gen, qs5, B, P.n) for _ in range(2)])
+            hint = rnd(gen, qs5, Ld, 2, P.n)
+            work = torch.empty((Ld, B, P.n, P.T), dtype=torch.int64, device="cuda")
+            out = torch.empty_like(add)
+            slab = B * P.n * P.T * 8
+            ms = timeit(lambda: L.lolhip_keyswitch_batch(P._h, st, ptr(c2), base, ptr(hint), 2, ptr(add), ptr(out), ptr(work), B))
+            report("keyswitch", f"m=2^{lm_} T=2 q~2^20 base={base} L={Ld} B={B}", ms, B, 5 * slab)
+            ms = timeit(lambda: L.lolhip_decompose_batch(P._h, st, ptr(c2), base, ptr(work), B))
+            report("  decompose", f"L={Ld}", ms, B, (1 + Ld) * slab)
+            ms = timeit(lambda: L.lolhip_crt_batch(P._h, st, ptr(work), Ld * B))
+            report("  crt(digits)", f"L={Ld}", ms, B * Ld, 2 * Ld * slab)
+            ms = timeit(lambda: L.lolhip_knapsack_batch(P._h, st, ptr(work), Ld, ptr(hint), 2, ptr(add), ptr(out), B))
+            report("  knapsack", f"L={Ld} K=2", ms, B, (Ld + 4) * slab)
+    # ---- rescale: drop the first of four 59-bit moduli at m = 2^15 --------------------------
+    qs = good_qs(2 ** 15, 2 ** 59, 4)
+    P = lol_amd.Plan([(2, 15)], qs)
+    B = 256
+    c = rnd(gen, qs, B, P.n)
+    out = torch.empty((B, P.n, 3), dtype=torch.int64, device="cuda")
+    ms = timeit(lambda: L.lolhip_rescale_drop_batch(P._h, st, ptr(c), ptr(out), B))
+    report("rescale_drop", f"m=2^15 T=4->3 B={B}", ms, B, B * P.n * 7 * 8)
+
+
+if __name__ == "__main__":
+    main()

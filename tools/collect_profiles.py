@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""tools/collect_profiles.py — condense gpurun_out/refresh/ (written by tools/refresh_profiles.sh on
+the GPU box) into the committed files under profiles/."""
+import csv, glob, json, os, re, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "refresh")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def pmc(dirname, pat="k_pow2"):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(SRC, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+# 1. bench line + kernel stats of the same command
+bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
+rows = []
+for f in glob.glob(os.path.join(SRC, "prof", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append([re.sub(r"\(.*", "", r["Name"])[:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+rows.sort(key=lambda r: -float(r[2]))
+with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+    w.writerows(rows)
+
+# 2. HBM traffic, calibrated on crt (known read volume), separate passes per counter
+B, n = 4096, 8192
+known_kb = B * n * 8 / 1024
+f_crt, w_crt = pmc("pmc_crt_FETCH_SIZE")["FETCH_SIZE"], pmc("pmc_crt_WRITE_SIZE")["WRITE_SIZE"]
+f_pm, w_pm = pmc("pmc_polymul_FETCH_SIZE")["FETCH_SIZE"], pmc("pmc_polymul_WRITE_SIZE")["WRITE_SIZE"]
+factor = known_kb / f_crt[0]
+read_b, write_b = f_pm[0] * factor * 1024, w_pm[0] * 1024
+alg = 3 * n * 8 * B
+traffic = {
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section); values are KB. "
+              "FETCH_SIZE under-reports wide streaming reads on gfx950; the factor is CALIBRATED on k_pow2<13,0> (crt in place), whose read "
+              "volume is known exactly (4096*8192*8 B). WRITE_SIZE needs no correction (crt writes exactly that volume and WRITE_SIZE reports it).",
+    "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- tools/bench_kernels 14 1 4096 {crt,polymul} 5  (and --pmc WRITE_SIZE); tools/refresh_profiles.sh",
+    "calibration_kernel": {"name": "k_pow2<13,0,1>", "known_read_KB": known_kb, "FETCH_SIZE_KB": f_crt[0], "factor": factor, "WRITE_SIZE_KB": w_crt[0]},
+    "k_pow2_polymul": {"FETCH_SIZE_KB": f_pm[0], "WRITE_SIZE_KB": w_pm[0], "dispatches_averaged": f_pm[1], "read_bytes": int(read_b), "write_bytes": int(write_b),
+                       "note": "includes the register-spill scratch of the 64-bit fused kernel (write-back through L2)"},
+    "k_pow2_polymul_hbm_bytes_per_launch": int(read_b + write_b),
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": round((read_b + write_b) / alg, 4),
+}
+json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+bench["roofline"]["traffic"] = traffic["k_pow2_polymul_hbm_bytes_per_launch"]
+json.dump(bench, open(os.path.join(DST, f"{tag}_bench.json"), "w"), ensure_ascii=False)
+
+# 3. SQ counters of the fused kernel
+sq = {}
+for d in ("pmc_sq1", "pmc_sq2"):
+    sq.update({k: v[0] for k, v in pmc(d).items()})
+with open(os.path.join(DST, f"{tag}_pmc_polymul_sq.txt"), "w") as fh:
+    fh.write("# rocprofv3 --pmc (two passes), tools/bench_kernels 14 1 4096 polymul 5; mean per dispatch of k_pow2<13,2,1>\n")
+    for k in sorted(sq):
+        fh.write(f"{k:28s} {sq[k]:.6g}\n")
+    if "SQ_LDS_BANK_CONFLICT" in sq and "SQ_LDS_IDX_ACTIVE" in sq:
+        fh.write(f"# LDS bank-conflict cycles / LDS active cycles = {sq['SQ_LDS_BANK_CONFLICT'] / sq['SQ_LDS_IDX_ACTIVE']:.3f}\n")
+    if "SQ_ACTIVE_INST_VALU" in sq and "SQ_WAVE_CYCLES" in sq:
+        fh.write(f"# VALU-active share of wave-cycles = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES']:.3f} (4 waves/SIMD: 0.25 = VALU always busy)\n")
+
+# 4. pipeline kernels
+pl = os.path.join(SRC, "pipelines.jsonl")
+if os.path.exists(pl):
+    lines = [l for l in open(pl) if l.startswith("{")]
+    open(os.path.join(DST, f"{tag}_pipelines.jsonl"), "w").writelines(lines)
+print(json.dumps(bench["roofline"]), traffic["traffic_over_algorithmic"])
+print(open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv")).read()[:600])
