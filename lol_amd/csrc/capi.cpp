@@ -5,6 +5,7 @@
 // entry point needs a HIP device and says so when there is none.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -327,6 +328,21 @@ int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2
   rc = make_decomp(p->P, base, d); if (rc) return rc;
   if (K < 1 || K > 3 || B < 0 || (B > 0 && (!c2_pow || !hint || !out || !work))) return LOLHIP_ERR_INVALID;
   if (B == 0) return LOLHIP_OK;
+  const Plan& P = p->P;
+  // one fused pass when the plan is in the 32-bit class of the m = 2^k path (every q_t < 2^30)
+  if (P.is_pow2 && P.pow2.d_tw_fwd32 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
+      (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !getenv("LOLHIP_KEYSWITCH_UNFUSED")) {
+    KeySwitchLaunch l;
+    l.stream = (hipStream_t)stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;
+    l.T = P.T; l.L = P.pow2.L; l.tw_fwd32 = P.pow2.d_tw_fwd32; l.mod = P.d_mod; l.dp = d;
+    l.magic32 = 1;
+    if (base >= 2) {
+      int lg = 0;
+      while (((u64)1 << lg) < (u64)base) ++lg;
+      l.magic32 = (uint32_t)((((u64)1 << 32) * (((u64)1 << lg) - (u64)base)) / (u64)base) + 1;
+    }
+    return launch_keyswitch_fused(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+  }
   if (launch_decompose((hipStream_t)stream, c2_pow, work, B, p->P.n, d, p->P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
   rc = lolhip_crt_batch(p, stream, work, (int64_t)d.L * B);          // all L*B digit polynomials in one launch
   if (rc) return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include "pipeline.h"
 #include "plan.h"
 
 namespace lolhip {
@@ -22,6 +23,23 @@ struct Pow2Launch {
 };
 // mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
 hipError_t launch_pow2(const Pow2Launch& a, int mode);
+
+// fused key switch (m = 2^k, 32-bit arithmetic class, two hint coefficients)
+struct KeySwitchLaunch {
+  hipStream_t stream;
+  const i64* c2;        // [B][n][T] powerful basis
+  const i64* hint;      // [L][2][n][T] CRT basis
+  const i64* addend;    // [2][B][n][T] CRT basis or null
+  i64* out;             // [2][B][n][T]
+  i64 B;
+  int T;
+  int L;                // n = 2^L
+  const uint32_t* tw_fwd32;
+  const ModCtx* mod;
+  DecompParams dp;
+  uint32_t magic32;     // 32-bit invariant-divisor constant of dp.base
+};
+hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a);
 
 struct GenericLaunch {
   hipStream_t stream;

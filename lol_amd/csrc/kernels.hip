@@ -920,6 +920,185 @@ hipError_t launch_pow2(const Pow2Launch& a, int mode) {
 }
 
 // =============================================================================
+// fused key switch (m = 2^k, every modulus < 2^30):
+//   out_k = addend_k + sum_j crt(reduce(digit_j(c2))) * hint_jk,  k = 0, 1
+// `switch` of lol-apps SymmSHE.hs:312-314 in ONE pass: what the reference does as
+// decompose -> reduce -> adviseCRT -> knapsack over boxed vectors, and the unfused path here as
+// three launches through an [L][B][n][T] digit slab (3 + 4L slab passes), reads c2 once per
+// target component (L2 hits after the first), the addends once, and writes the two outputs
+// once: 5 slab passes.  One workgroup item = (ciphertext b, target component s); the digit
+// loop is a run-time loop around one register-resident forward transform; the two
+// accumulators (32 VGPRs) stay in registers in the transform's output layout.
+// =============================================================================
+template <int L>
+__global__ void __launch_bounds__(pow2_threads(L), 4)
+k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64* addend, i64* out, i64 B, int T,
+            const u32* __restrict__ tw_fwd, const ModCtx* __restrict__ mod, DecompParams dp, u32 magic32, int xcd_map) {
+  constexpr int AR = 2;
+  constexpr int K = 2;
+  using S = Sched<L>;
+  using V = u32;
+  constexpr int n = 1 << L;
+  constexpr int NT = 1 << (L - R);
+  constexpr int PPW = NT >= 256 ? 1 : 256 / NT;
+  constexpr int LDSW = n + n / 16 + twl_words(n);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  V* lds = reinterpret_cast<V*>(smem) + (threadIdx.x / NT) * LDSW;
+  V* lds_tw = lds + n + n / 16;
+  const int tau = threadIdx.x % NT;
+
+  const i64 item0 = (i64)blockIdx.x * PPW;
+  const int slot = (PPW == 1) ? 0 : (int)(threadIdx.x / NT);
+  const i64 item = item0 + slot;
+  i64 b, b0; int s;
+  if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); s = r >> 3; b0 = b; }
+  else { b = item / T; s = (int)(item % T); b0 = item0 / T; }
+  if constexpr (PPW == 1) {
+    s = __builtin_amdgcn_readfirstlane(s);
+    b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
+  }
+  b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
+  const ModCtx ms = mod[s];
+  const QK32 qk(ms.q);
+  const u32 mu32 = (u32)(ms.mu >> 32);                   // floor(2^32 / q_s)
+
+  const u64 slab = (u64)B * n * T;                       // elements per [B][n][T] slab
+  const u64 win = (u64)(B - b0) * n * T * 8;
+  const u32 wbytes = win > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)win;
+  const size_t wbase = (size_t)b0 * n * T;
+  const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(c2 + wbase), 0, wbytes, 0x00020000);
+  const rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hint, 0, (u32)dp.L * K * n * (u32)T * 8u, 0x00020000);
+  const rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + wbase), 0, wbytes, 0x00020000);
+  const rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + slab + wbase), 0, wbytes, 0x00020000);
+  const rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend + wbase : nullptr), 0, addend ? wbytes : 0, 0x00020000);
+  const rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(addend ? addend + slab + wbase : nullptr), 0, addend ? wbytes : 0, 0x00020000);
+  TwCtxT<V> tw;
+  tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * 8u, 0x00020000);
+  tw.inv = tw.fwd;
+  tw.comp = (u32)s * (u32)n * 8u;
+  tw.pf = tw_fwd + (size_t)s * n * 2;
+  tw.pi = tw.pf;
+  tw.lds_tw = lds_tw;
+  tw.sc0 = 0; tw.sc1 = 0;
+  if constexpr (L >= TWL_MIN_L) tw_fill_lds<NT>(lds_tw, tw.fwd, tw.comp, n, tau);
+
+  constexpr Lay LIO = S::io();
+  constexpr Lay LFIN = S::final_layout();
+  const u32 uT8 = (u32)T * 8u;
+  const u32 pofs0 = (u32)(b - b0) * (u32)n * (u32)T * 8u;                 // this ciphertext inside the window, component 0
+  const u32 off_io = pofs0 + (u32)xthr<LIO>(tau) * uT8;                   // + t*8 per source component
+  const u32 off_fin = pofs0 + (u32)s * 8u + (u32)xthr<LFIN>(tau) * uT8;   // outputs / addends
+  const u32 off_h = (u32)s * 8u + (u32)xthr<LFIN>(tau) * uT8;             // hint polynomials (no batch axis)
+  const u32 hstride = (u32)n * uT8;                                       // bytes per hint polynomial
+
+  V acc0[E], acc1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { acc0[e] = 0; acc1[e] = 0; }
+  const int shift = (int)(dp.base / 2);
+  const u32 base = (u32)dp.base;
+  int j = 0;
+  for (int t = 0; t < T; ++t) {
+    const u32 qt = (u32)mod[t].q;
+    int vv[E];                                   // centred lift of component t, then its running quotient
+    {
+      u64 raw[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) raw[e] = load_u64(rc, off_io, (u32)lay_tab<LIO>.xr[e] * uT8 + (u32)t * 8u);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const u32 x = (u32)raw[e] + (qt & (u32)((i64)raw[e] >> 63));      // (-q,q) -> [0,q)
+        vv[e] = (2 * x < qt) ? (int)x : (int)x - (int)qt;                 // ZqBasic.hs:92-94
+      }
+    }
+    const int kt = dp.k[t];
+    for (int kd = 0; kd < kt; ++kd, ++j) {
+      V v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        int d;
+        if (kd + 1 < kt) {                       // centred remainder, quotient carries on (Numeric.hs:202-205,227-234)
+          const int a = vv[e] + shift;
+          const u32 nn = a >= 0 ? (u32)a : (u32)(-a - 1);
+          const u32 t1 = __umulhi(magic32, nn);
+          const u32 qq = (t1 + ((nn - t1) >> dp.sh1)) >> dp.sh2;
+          const int qd = a >= 0 ? (int)qq : -(int)qq - 1;
+          d = a - qd * (int)base - shift;
+          vv[e] = qd;
+        } else {
+          d = vv[e];
+        }
+        const u32 ad = d >= 0 ? (u32)d : (u32)(-d);                       // reduce into component s
+        u32 r = ad - __umulhi(ad, mu32) * qk.q;                           // [0, 2q)
+        r = csub32(r, qk.q);
+        v[e] = (d < 0 && r != 0) ? qk.q - r : r;
+      }
+      fwd_transform<AR, L, LIO, 10, true>(v, lds, tw, tau, qk);
+      const u32 hoff = (u32)j * (u32)K * hstride;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const u32 eo = (u32)lay_tab<LFIN>.xr[e] * uT8;
+        const u32 h0 = (u32)load_u64(rh, off_h, hoff + eo);
+        const u32 h1 = (u32)load_u64(rh, off_h, hoff + hstride + eo);
+        acc0[e] = csub32(acc0[e] + pmul<AR>(h0, v[e], ms, qk), qk.q);
+        acc1[e] = csub32(acc1[e] + pmul<AR>(h1, v[e], ms, qk), qk.q);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const u32 eo = (u32)lay_tab<LFIN>.xr[e] * uT8;
+    u32 r0 = acc0[e], r1 = acc1[e];
+    if (addend) {
+      r0 = csub32(r0 + from_i64<AR>((i64)load_u64(ra0, off_fin, eo), qk), qk.q);
+      r1 = csub32(r1 + from_i64<AR>((i64)load_u64(ra1, off_fin, eo), qk), qk.q);
+    }
+    store_u64(ro0, off_fin, eo, (u64)r0);
+    store_u64(ro1, off_fin, eo, (u64)r1);
+  }
+}
+
+template <int L>
+static hipError_t launch_keyswitch_L(const KeySwitchLaunch& a) {
+  constexpr int n = 1 << L;
+  constexpr int NT = 1 << (L - R);
+  constexpr int PPW = NT >= 256 ? 1 : 256 / NT;
+  constexpr int LDSW = n + n / 16 + twl_words(n);
+  const size_t lds_bytes = (size_t)PPW * LDSW * sizeof(u32);
+  const i64 items = a.B * a.T;
+  const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
+  const i64 grid = (items + PPW - 1) / PPW;
+  if (grid == 0) return hipSuccess;
+  static bool attr_set = false;
+  if (!attr_set && lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<L>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_keyswitch<L>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream, a.c2, a.hint,
+                     a.addend, a.out, a.B, a.T, a.tw_fwd32, a.mod, a.dp, a.magic32, xcd_map);
+  return hipGetLastError();
+}
+
+hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a) {
+  switch (a.L) {
+    case 4: return launch_keyswitch_L<4>(a);
+    case 5: return launch_keyswitch_L<5>(a);
+    case 6: return launch_keyswitch_L<6>(a);
+    case 7: return launch_keyswitch_L<7>(a);
+    case 8: return launch_keyswitch_L<8>(a);
+    case 9: return launch_keyswitch_L<9>(a);
+    case 10: return launch_keyswitch_L<10>(a);
+    case 11: return launch_keyswitch_L<11>(a);
+    case 12: return launch_keyswitch_L<12>(a);
+    case 13: return launch_keyswitch_L<13>(a);
+    case 14: return launch_keyswitch_L<14>(a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// =============================================================================
 // generic path: stage-program interpreter
 // =============================================================================
 

@@ -194,6 +194,34 @@ def test_gpu_keyswitch(gpu, cpuref, pps, qs, base):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L", range(4, 15))
+def test_gpu_keyswitch_fused_all_sizes(gpu, cpuref, monkeypatch, L):
+    """Every n = 2^L the fused single-pass kernel instantiates (moduli < 2^30), TrivGad and two
+    bases, odd batch sizes (ragged last workgroup), with and without addends; and the fused
+    and the three-launch path agree."""
+    m = 2 ** (L + 1)
+    qs = _qs_for(m, 2 ** 20, 2) + _qs_for(m, 2 ** 29, 1)
+    pps = [(2, L + 1)]
+    P, R = gpu.Plan(pps, qs), Params(pps, qs)
+    rng = np.random.default_rng(L)
+    for base, B in ((0, 3), (4, 1), (1000, 9 if L < 12 else 2)):
+        Ld = sum(sr.digit_counts(R, base))
+        c2 = R.random(rng, B)
+        c2[0, 0] = np.array(qs) - 1
+        c2[0, 1] = np.array(qs) // 2
+        hint = np.stack([np.stack([R.random(rng, 1)[0] for _ in range(2)]) for _ in range(Ld)])
+        add = np.stack([R.random(rng, B) for _ in range(2)])
+        want = sr.keyswitch(cpuref, R, c2, base, hint)
+        got = P.keySwitch(c2, base, hint)
+        assert np.array_equal(got, want), (L, base)
+        wadd = ((want.astype(object) + add) % np.array(qs, dtype=object)).astype(np.int64)
+        assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (L, base)
+        monkeypatch.setenv("LOLHIP_KEYSWITCH_UNFUSED", "1")
+        assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (L, base, "unfused")
+        monkeypatch.delenv("LOLHIP_KEYSWITCH_UNFUSED")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pps,qs", [c for c in CASES if len(c[1]) >= 2])
 def test_gpu_rescale(gpu, pps, qs):
     P, R = gpu.Plan(pps, qs), Params(pps, qs)
