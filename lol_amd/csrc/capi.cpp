@@ -71,6 +71,13 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
   a.stages = sp.d_stages; a.nstages = sp.nstages;
   a.consts = P.d_consts; a.cpc = P.consts_per_comp; a.mod = P.d_mod;
   a.scratch = P.d_scratch; a.scratch_bytes = P.scratch_bytes;
+  a.vec_ok = !getenv("LOLHIP_GENERIC_SCALAR");
+  for (const Stage& st : sp.stages)
+    if (st.kind != ST_DIAG && st.kind != ST_SCALE &&
+        !(st.d == 2 || st.d == 3 || st.d == 4 || st.d == 5 || st.d == 6 || st.d == 7 || st.d == 10 || st.d == 11 || st.d == 12 || st.d == 13))
+      a.vec_ok = false;
+  a.q32 = true;
+  for (u64 q : P.qs) if (q >= ((u64)1 << 32)) a.q32 = false;
   return launch_generic(a) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 

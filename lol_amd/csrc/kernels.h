@@ -54,6 +54,8 @@ struct GenericLaunch {
   const ModCtx* mod;
   u64* scratch;
   size_t scratch_bytes;
+  bool q32;          // every modulus < 2^32: 32-bit operand products in the dot-product stages
+  bool vec_ok;       // every stage's vector length is one the vector interpreter instantiates (p <= 13)
 };
 hipError_t launch_generic(const GenericLaunch& a);
 

@@ -1112,8 +1112,16 @@ __device__ __forceinline__ u64 smallmod(u64 k, u64 q) { return k < q ? k : k % q
 template <bool MAGIC> __device__ __forceinline__ int fdiv(int x, u64 M, int v) {
   if constexpr (MAGIC) return (int)(((u64)(u32)x * M) >> 40); else return x / v;
 }
-// out-of-place evaluation of one output element of one stage
-template <bool MAGIC>
+// a*b mod q for the generic path; Q32: both operands (and q) are below 2^32, one 32x32 product
+template <bool Q32> __device__ __forceinline__ u64 gmul(u64 a, u64 b, const ModCtx& mc) {
+  if constexpr (Q32) return rem128(0, (u64)(u32)a * (u32)b, mc);
+  else return mulmod(a, b, mc);
+}
+// out-of-place evaluation of one output element of one stage.
+// Q32 (every modulus of the plan < 2^32, the reference's own valid domain and below): the
+// dot products multiply 32-bit operands — one v_mad_u64_u32 per term instead of a 64x64->128
+// product — still accumulated exactly in 128 bits and reduced once.
+template <bool MAGIC, bool Q32>
 __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict__ in, int x,
                                           const u64* __restrict__ cst, const ModCtx& mc) {
   const u64 q = mc.q;
@@ -1121,7 +1129,7 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
   if (st.kind == ST_DIAG) {
     out = in[x];
   } else if (st.kind == ST_SCALE) {
-    return mulmod(in[x], cst[st.tw_off], mc);
+    return gmul<Q32>(in[x], cst[st.tw_off], mc);
   } else {
     const int rts = st.rts, d = st.d, p = st.p;
     const int xb = fdiv<MAGIC>(x, st.m_rts, rts);
@@ -1136,7 +1144,8 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
         u64 part = 0;
         int cnt = 0;
         for (int c = 0; c < d; ++c) {
-          acc += (unsigned __int128)vin[c * rts] * row[c];
+          if constexpr (Q32) acc += (unsigned __int128)((u64)(u32)vin[c * rts] * (u32)row[c]);
+          else acc += (unsigned __int128)vin[c * rts] * row[c];
           if (++cnt == 8) {   // 8 products of < 2^124 fit in 128 bits
             part = addmod(part, dot_reduce(acc, mc), q); acc = 0;
             cnt = 0;
@@ -1175,16 +1184,16 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
         for (int c = 0; c < d; ++c) {
           if (c <= i) le = addmod(le, vin[c * rts], q); else re = addmod(re, vin[c * rts], q);
         }
-        out = submod(mulmod(smallmod((u64)(p - 1 - i), q), le, mc), mulmod(smallmod((u64)(i + 1), q), re, mc), q);
+        out = submod(gmul<Q32>(smallmod((u64)(p - 1 - i), q), le, mc), gmul<Q32>(smallmod((u64)(i + 1), q), re, mc), q);
         break;
       }
       case ST_GINVDEC: {
         u64 s = 0, hi = 0;
         for (int c = 0; c < d; ++c) {
-          s = addmod(s, mulmod(smallmod((u64)(c + 1), q), vin[c * rts], mc), q);
+          s = addmod(s, gmul<Q32>(smallmod((u64)(c + 1), q), vin[c * rts], mc), q);
           if (c > i) hi = addmod(hi, vin[c * rts], q);
         }
-        out = submod(s, mulmod(smallmod((u64)p, q), hi, mc), q);
+        out = submod(s, gmul<Q32>(smallmod((u64)p, q), hi, mc), q);
         break;
       }
       default:
@@ -1193,12 +1202,12 @@ __device__ __forceinline__ u64 stage_eval(const Stage& st, const u64* __restrict
   }
   if (st.tw_off >= 0) {
     const int xd = fdiv<MAGIC>(x, st.m_twdiv, st.tw_div);
-    out = mulmod(out, cst[st.tw_off + xd - fdiv<MAGIC>(xd, st.m_twmod, st.tw_mod) * st.tw_mod], mc);
+    out = gmul<Q32>(out, cst[st.tw_off + xd - fdiv<MAGIC>(xd, st.m_twmod, st.tw_mod) * st.tw_mod], mc);
   }
   return out;
 }
 
-template <bool MAGIC>
+template <bool MAGIC, bool Q32>
 __global__ void __launch_bounds__(1024)
 k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
           const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw,
@@ -1230,13 +1239,180 @@ k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ st
       const Stage st = stages[s];
       for (int x = threadIdx.x; x < tot; x += blockDim.x) {
         const int pi = fdiv<MAGIC>(x, n_magic, n), xi = x - pi * n;
-        bufB[x] = stage_eval<MAGIC>(st, bufA + pi * n, xi, cst, mc);
+        bufB[x] = stage_eval<MAGIC, Q32>(st, bufA + pi * n, xi, cst, mc);
       }
       __syncthreads();
       u64* tmp = bufA; bufA = bufB; bufB = tmp;
     }
     for (int x = threadIdx.x; x < tot; x += blockDim.x)
       y[((size_t)b0 * n + x) * T + t] = (i64)bufA[x];
+    __syncthreads();
+  }
+}
+
+// -----------------------------------------------------------------------------
+// vector-per-thread interpreter for small primes (d <= 13): one thread owns one d-vector of a
+// stage (I (x) A_p (x) I_rts), reads it from LDS once, applies A_p in registers and writes it
+// back IN PLACE — one LDS buffer instead of ping-pong (more polynomials per CU), one LDS read
+// per coefficient instead of d, matrix entries through scalar loads (they are the same for
+// every vector), and the O(d) forms of L, L^-1, G, G^-1 (l.cpp:28-98, g.cpp:16-123) instead
+// of per-output sums.  Same stage program, same results as k_generic.
+// -----------------------------------------------------------------------------
+template <int D, bool Q32>
+__device__ __forceinline__ void stage_vec(const Stage& st, u64* __restrict__ buf, int vec, int n, u64 n_magic,
+                                          const u64* __restrict__ cst, const ModCtx& mc) {
+  const u64 q = mc.q;
+  const int rts = st.rts;
+  const int blk = fdiv<true>(vec, st.m_rts, rts), r = vec - blk * rts;
+  const int x0 = blk * D * rts + r;                       // position of element 0 in the (packed) buffer
+  u64* base = buf + x0;
+  u64 v[D], o[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
+  switch (st.kind) {
+    case ST_DFTP:
+    case ST_CRTP:
+    case ST_CRTPINV: {
+      const u64* M = cst + st.mat_off;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        unsigned __int128 acc = 0;
+        u64 part = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          if constexpr (Q32) acc += (unsigned __int128)((u64)(u32)v[c] * (u32)M[i * D + c]);
+          else acc += (unsigned __int128)v[c] * M[i * D + c];
+          if constexpr (D > 8) if (c == 7) { part = dot_reduce(acc, mc); acc = 0; }   // 8 products < 2^124 fit
+        }
+        o[i] = D > 8 ? addmod(part, dot_reduce(acc, mc), q) : dot_reduce(acc, mc);
+      }
+      break;
+    }
+    case ST_L: {                         // prefix sums (l.cpp:28-57)
+      u64 s = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) { s = addmod(s, v[i], q); o[i] = s; }
+      break;
+    }
+    case ST_LINV: {                      // adjacent differences (l.cpp:67-98)
+      o[0] = v[0];
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = submod(v[i], v[i - 1], q);
+      break;
+    }
+    case ST_GPOW: {                      // g.cpp:16-35
+      const u64 last = v[D - 1];
+      o[0] = addmod(v[0], last, q);
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = submod(addmod(v[i], last, q), v[i - 1], q);
+      break;
+    }
+    case ST_GDEC: {                      // g.cpp:37-58
+      u64 s = v[0];
+#pragma unroll
+      for (int c = 0; c < D; ++c) s = addmod(s, v[c], q);
+      o[0] = s;
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = submod(v[i], v[i - 1], q);
+      break;
+    }
+    case ST_GINVPOW: {                   // g.cpp:60-90: (p-1-i) * sum_{c<=i} - (i+1) * sum_{c>i}
+      u64 tot = 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) tot = addmod(tot, v[c], q);
+      u64 le = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        le = addmod(le, v[i], q);
+        const u64 re = submod(tot, le, q);
+        o[i] = submod(gmul<Q32>(smallmod((u64)(st.p - 1 - i), q), le, mc), gmul<Q32>(smallmod((u64)(i + 1), q), re, mc), q);
+      }
+      break;
+    }
+    case ST_GINVDEC: {                   // g.cpp:92-123: sum_c (c+1) v_c - p * sum_{c>i} v_c
+      u64 s = 0, tot = 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        s = addmod(s, gmul<Q32>(smallmod((u64)(c + 1), q), v[c], mc), q);
+        tot = addmod(tot, v[c], q);
+      }
+      const u64 pm = smallmod((u64)st.p, q);
+      u64 le = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        le = addmod(le, v[i], q);
+        o[i] = submod(s, gmul<Q32>(pm, submod(tot, le, q), mc), q);
+      }
+      break;
+    }
+    default:
+#pragma unroll
+      for (int i = 0; i < D; ++i) o[i] = v[i];
+  }
+  if (st.tw_off >= 0) {
+    const int pi = fdiv<true>(x0, n_magic, n);
+    const int xi0 = x0 - pi * n;                          // position inside its polynomial
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const int xd = fdiv<true>(xi0 + i * rts, st.m_twdiv, st.tw_div);
+      o[i] = gmul<Q32>(o[i], cst[st.tw_off + xd - fdiv<true>(xd, st.m_twmod, st.tw_mod) * st.tw_mod], mc);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) base[i * rts] = o[i];
+}
+
+// every vector length the vector interpreter instantiates (p-1 and p for p = 3..13)
+__host__ __device__ constexpr bool vec_len_ok(int d) {
+  return d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 10 || d == 11 || d == 12 || d == 13;
+}
+
+template <bool Q32>
+__global__ void __launch_bounds__(256)
+k_generic_vec(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
+              const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw, i64 ngroups) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* buf = reinterpret_cast<u64*>(smem);
+  const i64 items = ngroups * T;
+  const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
+  for (i64 item = blockIdx.x; item < items; item += gridDim.x) {
+    const i64 g = item / T;
+    const int t = (int)(item % T);
+    const i64 b0 = g * ppw;
+    const int np = (int)((B - b0) < ppw ? (B - b0) : ppw);
+    const int tot = np * n;
+    const ModCtx mc = mod[t];
+    const u64* cst = consts + (size_t)t * cpc;
+    for (int x = threadIdx.x; x < tot; x += blockDim.x) buf[x] = canon_in(y[((size_t)b0 * n + x) * T + t], mc.q);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+      const Stage st = stages[s];
+      if (st.kind == ST_DIAG || st.kind == ST_SCALE) {
+        for (int x = threadIdx.x; x < tot; x += blockDim.x) {
+          const int pi = fdiv<true>(x, n_magic, n);
+          buf[x] = stage_eval<true, Q32>(st, buf + pi * n, x - pi * n, cst, mc);   // element-wise: in place is safe
+        }
+      } else {
+        const int nvec = tot / st.d;
+        for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
+          switch (st.d) {
+            case 2: stage_vec<2, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 3: stage_vec<3, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 4: stage_vec<4, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 5: stage_vec<5, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 6: stage_vec<6, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 7: stage_vec<7, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 10: stage_vec<10, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 11: stage_vec<11, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 12: stage_vec<12, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            case 13: stage_vec<13, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
+            default: break;   // excluded on the host (vec_len_ok)
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int x = threadIdx.x; x < tot; x += blockDim.x) y[((size_t)b0 * n + x) * T + t] = (i64)buf[x];
     __syncthreads();
   }
 }
@@ -1249,6 +1425,21 @@ hipError_t launch_generic(const GenericLaunch& a) {
   u64* scratch = nullptr;
   size_t lds_bytes;
   i64 grid;
+  if (a.vec_ok && (size_t)a.n * sizeof(u64) <= 64 * 1024) {
+    // vector interpreter: one LDS buffer; pack small polynomials up to ~2048 coefficients
+    while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
+    lds_bytes = (size_t)ppw * a.n * sizeof(u64);
+    const i64 ngroups = (a.B + ppw - 1) / ppw;
+    grid = ngroups * a.T;
+    if (grid > 65536) grid = 65536;
+    if (a.q32)
+      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(256), lds_bytes, a.stream, a.y, a.B, a.T,
+                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
+    else
+      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(256), lds_bytes, a.stream, a.y, a.B, a.T,
+                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
+    return hipGetLastError();
+  }
   if (per_poly <= lds_budget) {
     // pack small polynomials: aim for >= 2048 coefficients per workgroup, <= 32 KiB per buffer
     while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
@@ -1258,15 +1449,22 @@ hipError_t launch_generic(const GenericLaunch& a) {
     if (grid > 65536) grid = 65536;
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
       if (e != hipSuccess) return e;
       attr_set = true;
     }
     // a workgroup that fills a CU's LDS on its own should also fill its SIMDs
     const int threads = ((size_t)ppw * a.n >= 4096) ? 1024 : ((size_t)ppw * a.n >= 1024 ? 512 : 256);
-    hipLaunchKernelGGL(k_generic<true>, dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.B, a.T, (int)a.n,
-                       a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, scratch, ngroups);
+    if (a.q32)
+      hipLaunchKernelGGL((k_generic<true, true>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.B, a.T,
+                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, scratch, ngroups);
+    else
+      hipLaunchKernelGGL((k_generic<true, false>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.B, a.T,
+                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, scratch, ngroups);
   } else {
     if (!a.scratch) return hipErrorInvalidValue;
     grid = a.B * a.T;
@@ -1274,10 +1472,10 @@ hipError_t launch_generic(const GenericLaunch& a) {
     if (grid > maxg) grid = maxg;
     if (grid < 1) return hipErrorInvalidValue;
     if (a.n < (1 << 20))
-      hipLaunchKernelGGL(k_generic<true>, dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
+      hipLaunchKernelGGL((k_generic<true, false>), dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
                          a.stages, a.nstages, a.consts, a.cpc, a.mod, 1, a.scratch, a.B);
     else
-      hipLaunchKernelGGL(k_generic<false>, dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
+      hipLaunchKernelGGL((k_generic<false, false>), dim3((unsigned)grid), dim3(1024), 0, a.stream, a.y, a.B, a.T, (int)a.n,
                          a.stages, a.nstages, a.consts, a.cpc, a.mod, 1, a.scratch, a.B);
   }
   return hipGetLastError();
