@@ -1274,17 +1274,18 @@ __device__ __forceinline__ void stage_vec(const Stage& st, u64* __restrict__ buf
     case ST_CRTP:
     case ST_CRTPINV: {
       const u64* M = cst + st.mat_off;
+      static_assert(D <= 16, "16 products below 2^124 (q < 2^62) fit in 128 bits");
 #pragma unroll
       for (int i = 0; i < D; ++i) {
         unsigned __int128 acc = 0;
-        u64 part = 0;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
           if constexpr (Q32) acc += (unsigned __int128)((u64)(u32)v[c] * (u32)M[i * D + c]);
           else acc += (unsigned __int128)v[c] * M[i * D + c];
-          if constexpr (D > 8) if (c == 7) { part = dot_reduce(acc, mc); acc = 0; }   // 8 products < 2^124 fit
         }
-        o[i] = D > 8 ? addmod(part, dot_reduce(acc, mc), q) : dot_reduce(acc, mc);
+        // Q32: the sum is below 16 * 2^64, so its high word is below q whenever q > 16: one division step
+        if (Q32 && q > 16) o[i] = rem128((u64)(acc >> 64), (u64)acc, mc);
+        else o[i] = dot_reduce(acc, mc);
       }
       break;
     }
