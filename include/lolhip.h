@@ -142,8 +142,15 @@ LOLHIP_API int lolhip_twace_crt_batch   (const lolhip_ext *x, void *stream, int6
 LOLHIP_API int lolhip_embed_pow_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
 LOLHIP_API int lolhip_embed_dec_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
 LOLHIP_API int lolhip_embed_crt_batch   (const lolhip_ext *x, void *stream, int64_t *hi_out, const int64_t *lo_in, int64_t B);
+/* coeffs (class Tensor, Tensor.hs:174; CPP/Extension.hs:90-93): the phi(m')/phi(m) coefficient
+ * vectors of each O_m' element with respect to the relative powerful (or decoding) basis,
+ * lo_out [phi(m')/phi(m)][B][n][T] <- hi_in [B][n'][T].  Vector i1 pairs with the relative basis
+ * element whose powerful-basis representation is the unit vector at index table5[i1*n]
+ * (powBasisPow, Tensor.hs:177: sum_i1 embed(coeffs_i1 x) * b_i1 = x, CycTests.hs:71-76). */
+LOLHIP_API int lolhip_coeffs_batch      (const lolhip_ext *x, void *stream, int64_t *lo_out, const int64_t *hi_in, int64_t B);
 /* host index tables: which 0 extIndicesPowDec[n] 1 extIndicesCRT[n'] 2 embedPow[n'] (-1 = zero)
- * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468) */
+ * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468)
+ * 5 extIndicesCoeffs[n'/n][n] flattened (Tensor.hs:472-477) */
 LOLHIP_API int64_t lolhip_ext_table(const lolhip_ext *x, int which, int32_t *out, int64_t len);
 
 /* --- ring-level pipelines of SymmSHE, device pointers -----------
@@ -206,7 +213,7 @@ enum {
 LOLHIP_API int lolhip_op_host(const lolhip_plan *p, int op, int64_t *y, const int64_t *b, int64_t B);
 enum {
   LOLHIP_EXT_TWACE_POWDEC = 0, LOLHIP_EXT_TWACE_CRT = 1, LOLHIP_EXT_EMBED_POW = 2,
-  LOLHIP_EXT_EMBED_DEC = 3, LOLHIP_EXT_EMBED_CRT = 4
+  LOLHIP_EXT_EMBED_DEC = 3, LOLHIP_EXT_EMBED_CRT = 4, LOLHIP_EXT_COEFFS = 5
 };
 LOLHIP_API int lolhip_ext_host(const lolhip_ext *x, int op, int64_t *out, const int64_t *in, int64_t B);
 

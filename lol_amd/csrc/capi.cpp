@@ -403,7 +403,7 @@ int lolhip_ext_create(const lolhip_plan* lo, const lolhip_plan* hi, lolhip_ext**
     };
     bool ok = up32(&X.d_twace_powdec, X.host.twace_powdec) && up32(&X.d_ext_crt, X.host.ext_crt) &&
               up32(&X.d_embed_pow, X.host.embed_pow) && up32(&X.d_embed_dec, X.host.embed_dec) &&
-              up32(&X.d_embed_crt, X.host.embed_crt);
+              up32(&X.d_embed_crt, X.host.embed_crt) && up32(&X.d_coeffs, X.host.coeffs);
     if (ok && !X.tweak.empty()) {
       ok = hipMalloc((void**)&X.d_tweak, X.tweak.size() * sizeof(i64)) == hipSuccess &&
            hipMemcpy(X.d_tweak, X.tweak.data(), X.tweak.size() * sizeof(i64), hipMemcpyHostToDevice) == hipSuccess;
@@ -415,7 +415,7 @@ int lolhip_ext_create(const lolhip_plan* lo, const lolhip_plan* hi, lolhip_ext**
 }
 void lolhip_ext_destroy(lolhip_ext* x) {
   if (!x) return;
-  void* ptrs[] = {x->X.d_twace_powdec, x->X.d_ext_crt, x->X.d_embed_pow, x->X.d_embed_dec, x->X.d_embed_crt, x->X.d_tweak};
+  void* ptrs[] = {x->X.d_twace_powdec, x->X.d_ext_crt, x->X.d_embed_pow, x->X.d_embed_dec, x->X.d_embed_crt, x->X.d_coeffs, x->X.d_tweak};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete x;
 }
@@ -428,6 +428,7 @@ int64_t lolhip_ext_table(const lolhip_ext* x, int which, int32_t* out, int64_t l
     case 2: src = &x->X.host.embed_pow; break;
     case 3: src = &x->X.host.embed_dec; break;
     case 4: src = &x->X.host.embed_crt; break;
+    case 5: src = &x->X.host.coeffs; break;
     default: return 0;
   }
   const int64_t avail = (int64_t)src->size();
@@ -447,6 +448,14 @@ static int ext_gather(const lolhip_ext* x, void* stream, int64_t* out, const int
 }
 int lolhip_twace_powdec_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const int64_t* hi_in, int64_t B) {
   return ext_gather(x, s, lo_out, hi_in, B, x ? x->X.d_twace_powdec : nullptr, false);
+}
+int lolhip_coeffs_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const int64_t* hi_in, int64_t B) {
+  if (!x) return LOLHIP_ERR_INVALID;
+  if (!x->X.d_coeffs) return LOLHIP_ERR_NO_DEVICE;
+  if (B < 0 || (B > 0 && (!lo_out || !hi_in))) return LOLHIP_ERR_INVALID;
+  const ExtPlan& X = x->X;
+  return launch_coeffs((hipStream_t)s, lo_out, hi_in, X.d_coeffs, B, X.host.phi, X.host.phi2, X.lo->T, X.lo->d_mod)
+                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 int lolhip_embed_pow_batch(const lolhip_ext* x, void* s, int64_t* hi_out, const int64_t* lo_in, int64_t B) {
   return ext_gather(x, s, hi_out, lo_in, B, x ? x->X.d_embed_pow : nullptr, true);
@@ -513,10 +522,10 @@ int lolhip_ext_host(const lolhip_ext* x, int op, int64_t* out, const int64_t* in
   if (!x) return LOLHIP_ERR_INVALID;
   if (!x->X.d_embed_pow) return LOLHIP_ERR_NO_DEVICE;
   if (B < 0 || (B > 0 && (!out || !in))) return LOLHIP_ERR_INVALID;
-  const bool to_hi = op >= LOLHIP_EXT_EMBED_POW;
+  const bool to_hi = op >= LOLHIP_EXT_EMBED_POW && op != LOLHIP_EXT_COEFFS;
   const int T = x->X.lo->T;
   const size_t bin = sizeof(int64_t) * (size_t)(B * (to_hi ? x->X.host.phi : x->X.host.phi2) * T);
-  const size_t bout = sizeof(int64_t) * (size_t)(B * (to_hi ? x->X.host.phi2 : x->X.host.phi) * T);
+  const size_t bout = sizeof(int64_t) * (size_t)(B * ((to_hi || op == LOLHIP_EXT_COEFFS) ? x->X.host.phi2 : x->X.host.phi) * T);
   if (bout == 0) return LOLHIP_OK;
   DevBuf di, dout;
   if (!di.alloc(bin) || !dout.alloc(bout)) return LOLHIP_ERR_HIP;
@@ -528,6 +537,7 @@ int lolhip_ext_host(const lolhip_ext* x, int op, int64_t* out, const int64_t* in
     case LOLHIP_EXT_EMBED_POW: rc = lolhip_embed_pow_batch(x, nullptr, dout.p, di.p, B); break;
     case LOLHIP_EXT_EMBED_DEC: rc = lolhip_embed_dec_batch(x, nullptr, dout.p, di.p, B); break;
     case LOLHIP_EXT_EMBED_CRT: rc = lolhip_embed_crt_batch(x, nullptr, dout.p, di.p, B); break;
+    case LOLHIP_EXT_COEFFS: rc = lolhip_coeffs_batch(x, nullptr, dout.p, di.p, B); break;
     default: return LOLHIP_ERR_INVALID;
   }
   if (rc) return rc;

@@ -215,6 +215,9 @@ bool build_ext_tables(const std::vector<PP>& pps, const std::vector<PP>& pps2, E
   i64 rel = X.phi2 / X.phi;
   X.twace_powdec.resize((size_t)X.phi);
   for (i64 i = 0; i < X.phi; ++i) X.twace_powdec[(size_t)i] = (int32_t)from_index_pair(tots, 0, i);
+  X.coeffs.resize((size_t)X.phi2);     // Tensor.hs:472-477
+  for (i64 i1 = 0; i1 < rel; ++i1)
+    for (i64 i0 = 0; i0 < X.phi; ++i0) X.coeffs[(size_t)(i1 * X.phi + i0)] = (int32_t)from_index_pair(tots, i1, i0);
   X.ext_crt.resize((size_t)X.phi2);
   for (i64 k = 0; k < X.phi2; ++k) X.ext_crt[(size_t)k] = (int32_t)from_index_pair(tots, k % rel, k / rel);
   X.embed_pow.resize((size_t)X.phi2);

@@ -62,6 +62,7 @@ struct ExtTables {
   std::vector<int32_t> embed_pow;      // [phi2]  source index in O_m or -1 (zero)
   std::vector<int32_t> embed_dec;      // [phi2]  source index, -1 zero; bit 30 set => negate
   std::vector<int32_t> embed_crt;      // [phi2]  baseIndicesCRT
+  std::vector<int32_t> coeffs;         // [phi2/phi][phi] extIndicesCoeffs: out[i1][i0] = in[idx[i1*phi + i0]]
 };
 static const int32_t EMBED_NEG_FLAG = 1 << 30;
 bool build_ext_tables(const std::vector<PP>& pps, const std::vector<PP>& pps2, ExtTables& out);

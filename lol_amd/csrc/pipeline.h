@@ -31,4 +31,8 @@ hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint,
 hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, const RescaleParams& p,
                           const ModCtx* mod);
 
+// coeffs (Extension.hs:90-93): out[i1][b][i0][t] = in[b][idx[i1*n_lo + i0]][t]
+hipError_t launch_coeffs(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_lo, i64 n_hi, int T,
+                         const ModCtx* mod);
+
 }  // namespace lolhip

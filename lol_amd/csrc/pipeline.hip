@@ -192,4 +192,35 @@ hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, c
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// coeffs: the phi(m')/phi(m) coefficient vectors of an O_m' element over O_m, powerful or
+// decoding basis (class Tensor `coeffs`, Tensor.hs:174; CPP/Extension.hs:90-93; table
+// extIndicesCoeffs, Tensor.hs:472-477).  A pure permutation: one read, one write.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_coeffs(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __restrict__ idx, i64 B, u32 n_lo, u32 n_hi,
+         int T, const ModCtx* __restrict__ mod) {
+  const i64 slab = B * n_lo * T;                    // one output vector over the whole batch
+  const i64 total = B * n_hi * T;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  const u32 per = n_lo * (u32)T;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const i64 i1 = g / slab;
+    const i64 w = g - i1 * slab;                    // position inside output vector i1: (b, i0, t)
+    const i64 b = w / per;
+    const u32 r = (u32)(w - b * per);
+    const u32 i0 = r / (u32)T, t = r - i0 * (u32)T;
+    const int32_t e = idx[i1 * n_lo + i0];
+    out[g] = (i64)canon_in(in[(b * n_hi + e) * T + t], mod[t].q);
+  }
+}
+
+hipError_t launch_coeffs(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_lo, i64 n_hi, int T,
+                         const ModCtx* mod) {
+  const i64 total = B * n_hi * T;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_coeffs, dim3(grid_for(total)), dim3(256), 0, s, out, in, idx, B, (u32)n_lo, (u32)n_hi, T, mod);
+  return hipGetLastError();
+}
+
 }  // namespace lolhip

@@ -99,7 +99,7 @@ struct ExtPlan {
   const Plan* hi = nullptr;    // index m'
   ExtTables host;
   int32_t *d_twace_powdec = nullptr, *d_ext_crt = nullptr, *d_embed_pow = nullptr,
-          *d_embed_dec = nullptr, *d_embed_crt = nullptr;
+          *d_embed_dec = nullptr, *d_embed_crt = nullptr, *d_coeffs = nullptr;
   std::vector<i64> tweak;      // [n'*T] AoS, twaceCRT's tweak vector (Extension.hs:110-125)
   i64* d_tweak = nullptr;
 };

@@ -32,7 +32,7 @@ _ERRNAMES = {ERR_INVALID: "invalid argument", ERR_MODULUS: "modulus out of range
              ERR_NOT_DIVISIBLE: "not divisible by g"}
 
 OP_CRT, OP_CRTINV, OP_MUL, OP_POLYMUL, OP_L, OP_LINV, OP_MULGPOW, OP_MULGDEC, OP_DIVGPOW, OP_DIVGDEC, OP_MULGCRT, OP_DIVGCRT = range(12)
-EXT_TWACE_POWDEC, EXT_TWACE_CRT, EXT_EMBED_POW, EXT_EMBED_DEC, EXT_EMBED_CRT = range(5)
+EXT_TWACE_POWDEC, EXT_TWACE_CRT, EXT_EMBED_POW, EXT_EMBED_DEC, EXT_EMBED_CRT, EXT_COEFFS = range(6)
 
 
 class LolHipError(RuntimeError):
@@ -103,7 +103,7 @@ def lib():
     L.lolhip_ext_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.lolhip_ext_destroy.argtypes = [vp]
     L.lolhip_ext_destroy.restype = None
-    for nm in ("twace_powdec", "twace_crt", "embed_pow", "embed_dec", "embed_crt"):
+    for nm in ("twace_powdec", "twace_crt", "embed_pow", "embed_dec", "embed_crt", "coeffs"):
         getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, vp, i64]
     L.lolhip_ext_table.argtypes = [vp, ci, _i32p, i64]
     L.lolhip_ext_table.restype = i64
@@ -411,6 +411,22 @@ class Ext:
             import torch
             out = torch.empty((B, dst.n, dst.T), dtype=torch.int64, device=x.device)
         _check(getattr(lib(), f"lolhip_{name}_batch")(self._h, _stream(stream), _devptr(out), _devptr(x), B))
+        return out
+
+    def coeffs(self, x, out=None, stream=None):
+        """[n'/n][B][n][T] coefficient vectors over the relative powerful/decoding basis (Tensor.hs:174)."""
+        rel = self.hi.n // self.lo.n
+        if isinstance(x, np.ndarray):
+            x, xp = _np(x)
+            B = self.hi._batch(x)
+            res = np.zeros((rel, B, self.lo.n, self.lo.T), dtype=np.int64)
+            _check(lib().lolhip_ext_host(self._h, EXT_COEFFS, res.ctypes.data_as(_i64p), xp, B))
+            return res
+        B = self.hi._batch_t(x)
+        if out is None:
+            import torch
+            out = torch.empty((rel, B, self.lo.n, self.lo.T), dtype=torch.int64, device=x.device)
+        _check(lib().lolhip_coeffs_batch(self._h, _stream(stream), _devptr(out), _devptr(x), B))
         return out
 
     def twacePowDec(self, x, out=None, stream=None): return self._run(EXT_TWACE_POWDEC, "twace_powdec", x, False, out, stream)

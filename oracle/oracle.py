@@ -178,6 +178,12 @@ class CpuRef:
     def twace_crt(self, P, P2, y):
         return self._per_comp(P2, P.n, y, lambda a, q: lm.twace_crt(P.pps, P2.pps, a, q))
 
+    def coeffs(self, P, P2, y):
+        """class Tensor `coeffs` (Tensor.hs:174; CPP/Extension.hs:90-93): [n'/n][B][n][T]."""
+        idx = np.array(lm.ext_indices_coeffs(P.pps, P2.pps), dtype=np.int64)       # [rel][n]
+        y = np.ascontiguousarray(y, dtype=np.int64).reshape(-1, P2.n, P2.T)
+        return np.ascontiguousarray(np.moveaxis(y[:, idx, :], 1, 0))                # y[b, idx[i1,i0], t]
+
 
 class CTRef:
     """The reference's own C++ (lol-cpp CT), one polynomial per call.

@@ -251,6 +251,17 @@ def test_twace_embed_vs_oracle(gpu, cpuref, m, m2, q):
     assert np.array_equal(X.embedCRT(lo), Ph.crt(X.embedPow(Pl.crtInv(lo))))
     assert np.array_equal(X.twaceCRT(hi), Pl.crt(X.twacePowDec(Ph.crtInv(hi))))
     assert np.array_equal(X.embedDec(lo), Ph.lInv(X.embedPow(Pl.l(lo))))
+    # coeffs (Tensor.hs:174) and prop_coeffsBasis (CycTests.hs:71-76) with the GPU on both sides
+    cs = X.coeffs(hi)
+    assert np.array_equal(cs, cpuref.coeffs(Rl, Rh, hi))
+    assert np.array_equal(cs[0], X.twacePowDec(hi))                       # vector 0 is the twace gather
+    if Rh.n <= 4096:
+        acc = np.zeros_like(hi)
+        tab = X.table(5).reshape(-1, Rl.n)
+        for i1 in range(tab.shape[0]):
+            basis = np.zeros_like(hi); basis[:, tab[i1, 0], :] = 1
+            acc = (acc + Ph.polymul(X.embedPow(cs[i1]), basis)) % np.array(qs)
+        assert np.array_equal(acc, hi)
 
 
 # ---------------------------------------------------------------------------------------

@@ -76,6 +76,7 @@ def test_extension_tables(lolhip, m, m2):
     assert list(X.table(2)) == [j1 if j0 == 0 else -1 for (j0, j1) in lm.base_indices_pow(a, b)]
     assert list(X.table(3)) == [(-1 if e is None else (e[0] | ((1 << 30) if e[1] else 0))) for e in lm.base_indices_dec(a, b)]
     assert list(X.table(4)) == lm.base_indices_crt(a, b)
+    assert list(X.table(5)) == [e for row in lm.ext_indices_coeffs(a, b) for e in row]
 
 
 def test_plan_without_crt_basis(lolhip):

@@ -185,3 +185,25 @@ def test_tensor_two_index_properties(cpuref, m, m2, qs):
     # twace of a divisible-by-g element commutes with divG when m = m'
     if m == m2:
         assert np.array_equal(cpuref.twace_powdec(Pl, Ph, hi), hi)
+
+
+@pytest.mark.parametrize("m,m2,q", [(4, 12, 13), (3, 21, 43), (8, 8, 17), (1, 8, 17), (7, 63, 127), (12, 60, 61)])
+def test_coeffs_against_the_relative_powerful_basis(cpuref, m, m2, q):
+    """prop_coeffsBasis (CycTests.hs:71-76): sum_i embed(coeffs_i x) * b_i = x, where b_i is the
+    i-th relative powerful-basis element — in the powerful basis of O_m' the unit vector at
+    fromIndexPair (i, 0) (powBasisPow, Tensor.hs:177 over :472-477).  Ring products by the
+    C++-pinned poly-mul."""
+    a, b = lm.factor_pps(m), lm.factor_pps(m2)
+    Rl, Rh = Params(a, [q]), Params(b, [q])
+    rng = np.random.default_rng(m2)
+    x = Rh.random(rng, 2)
+    cs = cpuref.coeffs(Rl, Rh, x)
+    idx = lm.ext_indices_coeffs(a, b)
+    assert cs.shape == (Rh.n // Rl.n, 2, Rl.n, 1)
+    assert sorted(e for row in idx for e in row) == list(range(Rh.n))          # a permutation of O_m'
+    acc = np.zeros_like(x)
+    for i1, row in enumerate(idx):
+        basis = np.zeros_like(x)
+        basis[:, row[0], :] = 1
+        acc = (acc + cpuref.polymul(Rh, cpuref.embed_pow(Rl, Rh, cs[i1]), basis).reshape(x.shape)) % q
+    assert np.array_equal(acc, x)
