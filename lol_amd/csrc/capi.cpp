@@ -573,13 +573,13 @@ struct PlanCache {
     return p;
   }
 };
-PlanCache& cache() { static PlanCache c; return c; }
+PlanCache* cache() { static PlanCache c; return &c; }
 
 int check_totm(const lolhip_plan* p, int64_t totm) { return (p && p->P.n == totm) ? LOLHIP_OK : LOLHIP_ERR_INVALID; }
 
 int dropin_prime(int op, int16_t T, int64_t* y, int64_t totm, lolhip_pp* pe, int16_t npe, int64_t* qs) {
   int rc;
-  lolhip_plan* p = cache().get(pe, npe, qs, T, nullptr, nullptr, &rc);
+  lolhip_plan* p = cache()->get(pe, npe, qs, T, nullptr, nullptr, &rc);
   if (rc) return rc;
   if ((rc = check_totm(p, totm))) return rc;
   return lolhip_op_host(p, op, y, nullptr, 1);
@@ -592,7 +592,7 @@ void tensorCRTRq(int16_t T, int64_t* y, int64_t totm, lolhip_pp* pe, int16_t npe
   std::vector<int64_t> om;
   for (int k = 0; k < npe; ++k) for (int t = 0; t < T; ++t) om.push_back(ru[k][T + t]);
   int rc;
-  lolhip_plan* p = cache().get(pe, npe, qs, T, npe ? om.data() : nullptr, nullptr, &rc);
+  lolhip_plan* p = cache()->get(pe, npe, qs, T, npe ? om.data() : nullptr, nullptr, &rc);
   if (!rc) rc = check_totm(p, totm);
   if (!rc) rc = lolhip_op_host(p, LOLHIP_OP_CRT, y, nullptr, 1);
   g_last_status = rc;
@@ -611,7 +611,7 @@ void tensorCRTInvRq(int16_t T, int64_t* y, int64_t totm, lolhip_pp* pe, int16_t 
     om.push_back((int64_t)w);
   }
   lolhip_plan* p = nullptr;
-  if (!rc) p = cache().get(pe, npe, qs, T, npe ? om.data() : nullptr, mhatInv, &rc);
+  if (!rc) p = cache()->get(pe, npe, qs, T, npe ? om.data() : nullptr, mhatInv, &rc);
   if (!rc) rc = check_totm(p, totm);
   if (!rc) rc = lolhip_op_host(p, LOLHIP_OP_CRTINV, y, nullptr, 1);
   g_last_status = rc;
@@ -620,7 +620,7 @@ void tensorCRTInvRq(int16_t T, int64_t* y, int64_t totm, lolhip_pp* pe, int16_t 
 void mulRq(int16_t T, int64_t* a, int64_t* b, int64_t totm, int64_t* qs) {
   // no prime powers in this signature: use the index-1 plan (n = 1) over totm "polynomials"
   int rc;
-  lolhip_plan* p = cache().get(nullptr, 0, qs, T, nullptr, nullptr, &rc);
+  lolhip_plan* p = cache()->get(nullptr, 0, qs, T, nullptr, nullptr, &rc);
   if (!rc) rc = lolhip_op_host(p, LOLHIP_OP_MUL, a, b, totm);
   g_last_status = rc;
 }
