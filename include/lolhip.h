@@ -148,6 +148,17 @@ LOLHIP_API int lolhip_embed_crt_batch   (const lolhip_ext *x, void *stream, int6
  * element whose powerful-basis representation is the unit vector at index table5[i1*n]
  * (powBasisPow, Tensor.hs:177: sum_i1 embed(coeffs_i1 x) * b_i1 = x, CycTests.hs:71-76). */
 LOLHIP_API int lolhip_coeffs_batch      (const lolhip_ext *x, void *stream, int64_t *lo_out, const int64_t *hi_in, int64_t B);
+/* evalLin (lol Linear.hs:75-79): apply the E-linear function R -> S given by its values
+ * ys_i in S on the relative decoding basis of R/E:
+ *     out = sum_i ys_i * embed (coeffsDec_i r)
+ * x_er: extension E in R, x_es: extension E in S (same plan for E in both).  r_dec [B][n_R][T]
+ * in the decoding basis of R; ys_crt [n_R/n_E][n_S][T] in the CRT basis of S (what linearDec
+ * stores, Linear.hs:68-72); out [B][n_S][T] in the CRT basis of S.  work: device scratch of
+ * (n_R/n_E) * B * (n_E + n_S) * T int64.  A composition of the kernels above: coeffs gather,
+ * embedDec, l, crt over all (n_R/n_E)*B polynomials at once, knapsack. */
+LOLHIP_API int lolhip_evallin_batch(const lolhip_ext *x_er, const lolhip_ext *x_es, void *stream,
+                                    const int64_t *r_dec, const int64_t *ys_crt, int64_t *out,
+                                    int64_t *work, int64_t B);
 /* host index tables: which 0 extIndicesPowDec[n] 1 extIndicesCRT[n'] 2 embedPow[n'] (-1 = zero)
  * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468)
  * 5 extIndicesCoeffs[n'/n][n] flattened (Tensor.hs:472-477) */

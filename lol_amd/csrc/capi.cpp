@@ -457,6 +457,30 @@ int lolhip_coeffs_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const int
   return launch_coeffs((hipStream_t)s, lo_out, hi_in, X.d_coeffs, B, X.host.phi, X.host.phi2, X.lo->T, X.lo->d_mod)
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
+int lolhip_evallin_batch(const lolhip_ext* x_er, const lolhip_ext* x_es, void* s, const int64_t* r_dec,
+                         const int64_t* ys_crt, int64_t* out, int64_t* work, int64_t B) {
+  if (!x_er || !x_es) return LOLHIP_ERR_INVALID;
+  const ExtPlan &ER = x_er->X, &ES = x_es->X;
+  if (!ER.d_coeffs || !ES.d_embed_dec) return LOLHIP_ERR_NO_DEVICE;
+  if (ER.host.phi != ES.host.phi || ER.lo->T != ES.lo->T || ER.lo->qs != ES.lo->qs || ER.lo->pps.size() != ES.lo->pps.size())
+    return LOLHIP_ERR_INVALID;                                     // the two extensions must share E
+  if (!ES.hi->has_crt) return LOLHIP_ERR_NO_CRT;
+  if (B < 0 || (B > 0 && (!r_dec || !ys_crt || !out || !work))) return LOLHIP_ERR_INVALID;
+  if (B == 0) return LOLHIP_OK;
+  const i64 rel = ER.host.phi2 / ER.host.phi;
+  const int T = ER.lo->T;
+  int64_t* tmp_e = work;                                           // [rel][B][n_E][T]
+  int64_t* tmp_s = work + rel * B * ER.host.phi * T;               // [rel][B][n_S][T]
+  const Plan* PS = ES.hi;                                          // the S-side plan
+  int rc = lolhip_coeffs_batch(x_er, s, tmp_e, r_dec, B);
+  if (!rc) rc = lolhip_embed_dec_batch(x_es, s, tmp_s, tmp_e, rel * B);
+  if (!rc) rc = run_prog(*PS, PS->prog_l, (hipStream_t)s, tmp_s, rel * B);                 // Dec -> Pow
+  if (!rc) rc = PS->is_pow2 ? run_pow2(*PS, 0, (hipStream_t)s, tmp_s, nullptr, nullptr, rel * B)
+                            : run_prog(*PS, PS->prog_crt, (hipStream_t)s, tmp_s, rel * B);
+  if (rc) return rc;
+  return launch_knapsack((hipStream_t)s, tmp_s, (int)rel, ys_crt, 1, nullptr, out, B, PS->n, PS->T, PS->d_mod)
+                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
 int lolhip_embed_pow_batch(const lolhip_ext* x, void* s, int64_t* hi_out, const int64_t* lo_in, int64_t B) {
   return ext_gather(x, s, hi_out, lo_in, B, x ? x->X.d_embed_pow : nullptr, true);
 }

@@ -105,6 +105,7 @@ def lib():
     L.lolhip_ext_destroy.restype = None
     for nm in ("twace_powdec", "twace_crt", "embed_pow", "embed_dec", "embed_crt", "coeffs"):
         getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, vp, i64]
+    L.lolhip_evallin_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
     L.lolhip_ext_table.argtypes = [vp, ci, _i32p, i64]
     L.lolhip_ext_table.restype = i64
     L.lolhip_op_host.argtypes = [vp, ci, _i64p, _i64p, i64]
@@ -428,6 +429,19 @@ class Ext:
             out = torch.empty((rel, B, self.lo.n, self.lo.T), dtype=torch.int64, device=x.device)
         _check(lib().lolhip_coeffs_batch(self._h, _stream(stream), _devptr(out), _devptr(x), B))
         return out
+
+    def evalLin(self, es: "Ext", r_dec, ys_crt, stream=None):
+        """sum_i ys_i * embed(coeffsDec_i r)  (Linear.hs:75-79): self = E in R, es = E in S;
+        r_dec [B][n_R][T] decoding basis, ys_crt [n_R/n_E][n_S][T] CRT basis -> [B][n_S][T] CRT basis."""
+        import torch
+        host, (r_dec, ys_crt) = Plan._stage(r_dec, ys_crt)
+        B, rel = self.hi._batch_t(r_dec), self.hi.n // self.lo.n
+        S = es.hi
+        work = torch.empty((rel * B * (self.lo.n + S.n) * S.T,), dtype=torch.int64, device=r_dec.device)
+        out = torch.empty((B, S.n, S.T), dtype=torch.int64, device=r_dec.device)
+        _check(lib().lolhip_evallin_batch(self._h, es._h, _stream(stream), _devptr(r_dec), _devptr(ys_crt),
+                                          _devptr(out), _devptr(work), B))
+        return Plan._unstage(host, out)
 
     def twacePowDec(self, x, out=None, stream=None): return self._run(EXT_TWACE_POWDEC, "twace_powdec", x, False, out, stream)
     def twaceCRT(self, x, out=None, stream=None): return self._run(EXT_TWACE_CRT, "twace_crt", x, False, out, stream)

@@ -147,3 +147,22 @@ def rescale_drop_first(P: Params, c):
         inv = pow(qa % q, -1, q)
         cols.append((((_obj(c[..., s]) - z) % q) * inv % q).astype(np.int64))
     return np.ascontiguousarray(np.stack(cols, axis=-1))
+
+
+# ---- E-linear functions (tunnelling) ----------------------------------------------------
+
+def evallin(cpu: CpuRef, PE: Params, PR: Params, PS: Params, r_dec, ys_crt):
+    """lol Linear.hs:75-79: evalLin (RD ys) r = sum (zipWith (*) ys (embed <$> coeffsDec r)).
+    r_dec [B][n_R][T] (decoding basis of R); ys_crt [n_R/n_E][n_S][T] (CRT basis of S, as
+    linearDec stores them, Linear.hs:68-72) -> [B][n_S][T] in the CRT basis of S.  embed of a
+    decoding-basis element is embedDec; the product needs the CRT basis: l (Dec -> Pow), crt."""
+    r_dec = np.asarray(r_dec)
+    B = r_dec.shape[0]
+    cs = cpu.coeffs(PE, PR, r_dec)                                       # [rel][B][n_E][T]
+    acc = np.zeros((B, PS.n, PS.T), dtype=np.int64)
+    for i in range(cs.shape[0]):
+        e = cpu.embed_dec(PE, PS, cs[i])
+        e = cpu.crt(PS, cpu.l(PS, np.ascontiguousarray(e))).reshape(B, PS.n, PS.T)
+        y = np.ascontiguousarray(np.broadcast_to(np.asarray(ys_crt)[i], (B, PS.n, PS.T)))
+        acc = _addmod(acc, cpu.mul(PS, np.ascontiguousarray(e), y).reshape(B, PS.n, PS.T), PS)
+    return acc

@@ -124,6 +124,58 @@ def test_keyswitch_with_a_noise_free_hint_multiplies_by_the_encoded_value(cpuref
     assert np.array_equal(out[0], want) and not out[1].any()
 
 
+EXT_CASES = [(4, 12, 12, 13), (3, 21, 21, 43), (1, 8, 8, 17), (4, 12, 20, 61), (3, 21, 15, 211), (8, 16, 40, 241)]   # (e, r, s, q)
+
+
+def _identity_ys(cpuref, PE, PR):
+    """values of the identity function on the relative decoding basis of R/E, CRT basis of R.
+    d_R = d_{R/E} (x) d_E under the index pairing of Tensor.hs:472-477, so the relative basis
+    element d_{R/E,i} = d_{R/E,i} * 1_E has decoding coordinates u_k at index (i, k), where u is
+    1 in E written in E's decoding basis (lInv of the powerful-basis unit vector)."""
+    idx = lm.ext_indices_coeffs(PE.pps, PR.pps)
+    one = np.zeros((1, PE.n, PE.T), dtype=np.int64)
+    one[0, 0, :] = 1
+    u = cpuref.linv(PE, one).reshape(PE.n, PE.T)
+    ys = np.zeros((len(idx), PR.n, PR.T), dtype=np.int64)
+    for i, row in enumerate(idx):
+        ys[i, row, :] = u
+    return cpuref.crt(PR, cpuref.l(PR, ys)).reshape(ys.shape)
+
+
+@pytest.mark.parametrize("e,r,s,q", EXT_CASES)
+def test_evallin_of_the_identity_and_linearity(cpuref, e, r, s, q):
+    """evalLin (linearDec ds) = id when ds is the relative decoding basis itself (the defining
+    property of linearDec, Linear.hs:62-72), and evalLin is additive in its function argument."""
+    PE, PR, PS = (Params(lm.factor_pps(m), [q]) for m in (e, r, s))
+    rng = np.random.default_rng(r * 7 + s)
+    x = PR.random(rng, 2)
+    got = sr.evallin(cpuref, PE, PR, PR, x, _identity_ys(cpuref, PE, PR))
+    assert np.array_equal(got, cpuref.crt(PR, cpuref.l(PR, x)).reshape(x.shape))
+    rel = PR.n // PE.n
+    y1 = np.stack([PS.random(rng, 1)[0] for _ in range(rel)])
+    y2 = np.stack([PS.random(rng, 1)[0] for _ in range(rel)])
+    f1, f2 = sr.evallin(cpuref, PE, PR, PS, x, y1), sr.evallin(cpuref, PE, PR, PS, x, y2)
+    f12 = sr.evallin(cpuref, PE, PR, PS, x, (y1 + y2) % q)
+    assert np.array_equal(f12, (f1 + f2) % q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e,r,s,q", EXT_CASES + [(128, 128 * 7, 128 * 13, 23297)])
+def test_gpu_evallin(gpu, cpuref, e, r, s, q):
+    qs = [q, lm.first_good_q(r * s // np.gcd(r, s), q)]
+    pe, pr, ps = (lm.factor_pps(m) for m in (e, r, s))
+    PE, PR, PS = (Params(p_, qs) for p_ in (pe, pr, ps))
+    GE, GR, GS = (gpu.Plan(p_, qs) for p_ in (pe, pr, ps))
+    XR, XS = gpu.Ext(GE, GR), gpu.Ext(GE, GS)
+    rng = np.random.default_rng(r + s)
+    x = PR.random(rng, 3)
+    ys = np.stack([PS.random(rng, 1)[0] for _ in range(PR.n // PE.n)])
+    assert np.array_equal(XR.evalLin(XS, x, ys), sr.evallin(cpuref, PE, PR, PS, x, ys))
+    if PR.n <= 2048:                                                   # identity function, GPU on both sides
+        ident = _identity_ys(cpuref, PE, PR)
+        assert np.array_equal(XR.evalLin(XR, x, ident), GR.crt(GR.l(x)))
+
+
 # ------------------------------------------------------------------------------------
 # GPU: liblolhip against the restatement, bit for bit
 # ------------------------------------------------------------------------------------
