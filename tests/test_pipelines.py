@@ -162,7 +162,8 @@ def test_evallin_of_the_identity_and_linearity(cpuref, e, r, s, q):
 @pytest.mark.gpu
 @pytest.mark.parametrize("e,r,s,q", EXT_CASES + [(128, 128 * 7, 128 * 13, 23297)])
 def test_gpu_evallin(gpu, cpuref, e, r, s, q):
-    qs = [q, lm.first_good_q(r * s // np.gcd(r, s), q)]
+    import math
+    qs = [q, lm.first_good_q(r * s // math.gcd(r, s), q)]
     pe, pr, ps = (lm.factor_pps(m) for m in (e, r, s))
     PE, PR, PS = (Params(p_, qs) for p_ in (pe, pr, ps))
     GE, GR, GS = (gpu.Plan(p_, qs) for p_ in (pe, pr, ps))
