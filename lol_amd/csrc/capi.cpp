@@ -95,6 +95,23 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
   return launch_pow2(l, mode) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
+// crt / crtInv of B polynomials through whichever path the plan has: the m = 2^k kernels,
+// the 2-power factor through them and the odd primes through the stage program, or the
+// stage program alone
+int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
+  if (P.is_pow2) return run_pow2(P, inverse ? 1 : 0, s, y, nullptr, nullptr, B);
+  if (P.pow2_part && !getenv("LOLHIP_NO_POW2_PART")) {
+    const int64_t blocks = B * (P.n >> P.pow2.L);       // contiguous 2^(e-1)-coefficient blocks
+    if (!inverse) {
+      int rc = run_pow2(P, 0, s, y, nullptr, nullptr, blocks);
+      return rc ? rc : run_prog(P, P.prog_crt_odd, s, y, B);
+    }
+    int rc = run_prog(P, P.prog_crtinv_odd, s, y, B);
+    return rc ? rc : run_pow2(P, 1, s, y, nullptr, nullptr, blocks);
+  }
+  return run_prog(P, inverse ? P.prog_crtinv : P.prog_crt, s, y, B);
+}
+
 int divg_ok(const Plan& P) {
   for (u64 v : P.oddrad_inv) if (v == 0) return 0;
   return 1;
@@ -156,15 +173,13 @@ int lolhip_crt_batch(const lolhip_plan* p, void* stream, int64_t* y, int64_t B) 
   int rc = need_device(p); if (rc) return rc;
   if (!p->P.has_crt) return LOLHIP_ERR_NO_CRT;
   if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
-  if (p->P.is_pow2) return run_pow2(p->P, 0, (hipStream_t)stream, y, nullptr, nullptr, B);
-  return run_prog(p->P, p->P.prog_crt, (hipStream_t)stream, y, B);
+  return do_crt(p->P, (hipStream_t)stream, y, B, false);
 }
 int lolhip_crtinv_batch(const lolhip_plan* p, void* stream, int64_t* y, int64_t B) {
   int rc = need_device(p); if (rc) return rc;
   if (!p->P.has_crt) return LOLHIP_ERR_NO_CRT;
   if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
-  if (p->P.is_pow2) return run_pow2(p->P, 1, (hipStream_t)stream, y, nullptr, nullptr, B);
-  return run_prog(p->P, p->P.prog_crtinv, (hipStream_t)stream, y, B);
+  return do_crt(p->P, (hipStream_t)stream, y, B, true);
 }
 int lolhip_mul_batch(const lolhip_plan* p, void* stream, int64_t* a, const int64_t* b, int64_t B) {
   int rc = need_device(p); if (rc) return rc;
@@ -196,10 +211,10 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   rc = LOLHIP_OK;
   if (hipMemcpyAsync(tmp, b, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
   if (!rc && c != a && hipMemcpyAsync(c, a, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
-  if (!rc) rc = run_prog(P, P.prog_crt, s, c, B);
-  if (!rc) rc = run_prog(P, P.prog_crt, s, tmp, B);
+  if (!rc) rc = do_crt(P, s, c, B, false);
+  if (!rc) rc = do_crt(P, s, tmp, B, false);
   if (!rc) rc = lolhip_mul_batch(p, stream, c, tmp, B);
-  if (!rc) rc = run_prog(P, P.prog_crtinv, s, c, B);
+  if (!rc) rc = do_crt(P, s, c, B, true);
   return rc;
 }
 
@@ -475,8 +490,7 @@ int lolhip_evallin_batch(const lolhip_ext* x_er, const lolhip_ext* x_es, void* s
   int rc = lolhip_coeffs_batch(x_er, s, tmp_e, r_dec, B);
   if (!rc) rc = lolhip_embed_dec_batch(x_es, s, tmp_s, tmp_e, rel * B);
   if (!rc) rc = run_prog(*PS, PS->prog_l, (hipStream_t)s, tmp_s, rel * B);                 // Dec -> Pow
-  if (!rc) rc = PS->is_pow2 ? run_pow2(*PS, 0, (hipStream_t)s, tmp_s, nullptr, nullptr, rel * B)
-                            : run_prog(*PS, PS->prog_crt, (hipStream_t)s, tmp_s, rel * B);
+  if (!rc) rc = do_crt(*PS, (hipStream_t)s, tmp_s, rel * B, false);
   if (rc) return rc;
   return launch_knapsack((hipStream_t)s, tmp_s, (int)rel, ys_crt, 1, nullptr, out, B, PS->n, PS->T, PS->d_mod)
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;

@@ -48,6 +48,21 @@ struct ProgBuilder {
   }
 };
 
+// emits every operation into the full program and, for prime powers other than the first,
+// into the odd-only program as well (diagonals fold per program, so the two are built
+// side by side rather than sliced out of one another)
+struct DualBuilder {
+  ProgBuilder* full; ProgBuilder* odd;
+  void dense(int kind, int p, int d, i64 rts, int wp_off, int mat_off) {
+    full->dense(kind, p, d, rts, wp_off); full->st.back().mat_off = mat_off;
+    if (odd) { odd->dense(kind, p, d, rts, wp_off); odd->st.back().mat_off = mat_off; }
+  }
+  void diag(int tw_off, i64 tw_div, i64 tw_mod) {
+    full->diag(tw_off, tw_div, tw_mod);
+    if (odd) odd->diag(tw_off, tw_div, tw_mod);
+  }
+};
+
 // ru-table accessor for component t of prime power k
 struct RuView {
   const std::vector<i64>& tab; int T; int t;
@@ -168,7 +183,8 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     return pool.add(tab);
   };
 
-  ProgBuilder crt, crtinv;
+  ProgBuilder crt, crtinv, crt_odd, crtinv_odd;
+  const bool split2 = K >= 2 && pps[0].p == 2;   // odd-only programs skip the first (2-power) factor
   if (P.has_crt) {
     i64 rts = 1;
     for (int k = 0; k < K; ++k) {
@@ -176,7 +192,7 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
       const i64 mprime = ipow(p, e - 1), phi = (p - 1) * mprime;
       for (int inv = 0; inv < 2; ++inv) {
         const std::vector<i64>& rutab = inv ? P.ruinv[(size_t)k] : P.ru[(size_t)k];
-        ProgBuilder& pb = inv ? crtinv : crt;
+        DualBuilder pb{inv ? &crtinv : &crt, (split2 && k >= 1) ? (inv ? &crtinv_odd : &crt_odd) : nullptr};
         // omega_p^j, j < p  (ru[j * p^(e-1)], crt.cpp:526 rustride = mprime)
         const int wp_off = per_comp([&](int t, std::vector<u64>& o) {
           RuView r{rutab, T, t};
@@ -218,13 +234,13 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
           }, (size_t)dim);
         };
         if (!inv) {
-          if (p != 2) { pb.dense(ST_CRTP, p, p - 1, rts, wp_off); pb.st.back().mat_off = mat_crt; }
+          if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off, mat_crt);
           if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
           i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
           int ecur = e1;
           for (int i = 0; i < e1; ++i) {
             const i64 rtsDim = rts1 * rtsScale;
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off); pb.st.back().mat_off = mat_dft;
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
             int off = dft_diag(ecur, ltsScale * p, twidRuStride);
             if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
             ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
@@ -236,11 +252,11 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
             const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
             int off = dft_diag(ecur, ltsScaleP, twidRuStride);
             if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off); pb.st.back().mat_off = mat_dft;
+            pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
             ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
           }
           if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
-          if (p != 2) { pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off); pb.st.back().mat_off = mat_crt; }
+          if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off, mat_crt);
         }
       }
       rts *= phi;
@@ -278,7 +294,13 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   for (int t = 0; t < T; ++t) P.host_consts.insert(P.host_consts.end(), pool.pool[(size_t)t].begin(), pool.pool[(size_t)t].end());
 
   P.is_pow2 = P.has_crt && K == 1 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
-  P.pow2.L = P.is_pow2 ? pps[0].e - 1 : 0;
+  P.pow2_part = P.has_crt && K >= 2 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
+  P.pow2.L = (P.is_pow2 || P.pow2_part) ? pps[0].e - 1 : 0;
+  if (P.pow2_part) {        // mhat^-1 is not in crtinv_odd: the 2-power inverse kernel folds it in
+    finish(crt_odd.st); finish(crtinv_odd.st);
+    P.prog_crt_odd.stages = crt_odd.st;
+    P.prog_crtinv_odd.stages = crtinv_odd.st;
+  }
   return LOLHIP_OK;
 }
 
@@ -309,14 +331,15 @@ int plan_upload(Plan& P) {
   int rc;
   if ((rc = upload(&P.d_mod, mods))) return rc;
   if ((rc = upload(&P.d_consts, P.host_consts))) return rc;
-  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
+  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
+                           &P.prog_crt_odd, &P.prog_crtinv_odd};
   for (auto* sp : progs) if ((rc = upload_prog(*sp))) return rc;
   if ((rc = upload(&P.d_gcrt, P.gcrt))) return rc;
   if ((rc = upload(&P.d_ginvcrt, P.ginvcrt))) return rc;
 
-  if (P.is_pow2) {
+  if (P.is_pow2 || P.pow2_part) {
     const int L = P.pow2.L;
-    const i64 n = P.n;
+    const i64 n = (i64)1 << L;          // length of the 2-power factor (= P.n for m = 2^k)
     std::vector<u64> fwd((size_t)(T * n * 2), 0), inv((size_t)(T * n * 2), 0), sc((size_t)(T * 2), 0);
     for (int t = 0; t < T; ++t) {
       const u64 q = P.qs[(size_t)t];
@@ -374,7 +397,8 @@ void plan_free_device(Plan& P) {
   P.d_tmp = nullptr; P.tmp_bytes = 0;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
-  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec};
+  StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
+                           &P.prog_crt_odd, &P.prog_crtinv_odd};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
   P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr; P.d_scratch = nullptr;
   P.pow2 = Pow2Tables();

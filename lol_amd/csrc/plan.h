@@ -83,6 +83,12 @@ struct Plan {
   u64* d_consts = nullptr;                  // generic-path constant pool, [T][consts_per_comp]
   int consts_per_comp = 0;
   StageProgram prog_crt, prog_crtinv, prog_l, prog_linv, prog_gpow, prog_gdec, prog_ginvpow, prog_ginvdec;
+  // m = 2^e * odd, 5 <= e <= 15: the 2-power tensor factor is innermost (tensor.h:46-73), i.e. it
+  // acts on contiguous blocks of 2^(e-1) coefficients — a batch of B*n/2^(e-1) short transforms
+  // for the m = 2^k kernels; these programs hold only the odd primes' stages (the inverse one
+  // without mhat^-1, which the 2-power inverse kernel folds in).
+  bool pow2_part = false;
+  StageProgram prog_crt_odd, prog_crtinv_odd;
   i64* d_gcrt = nullptr;                    // [n*T]
   i64* d_ginvcrt = nullptr;                 // [n*T]
   Pow2Tables pow2;

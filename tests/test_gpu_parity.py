@@ -218,6 +218,28 @@ def test_generic_indices(gpu, cpuref, m):
         assert np.array_equal(P.divGCRT(P.mulGCRT(y)), y)
 
 
+@pytest.mark.parametrize("m", [96, 160, 1728, 2912, 11648, 2 ** 12 * 3])
+def test_two_power_factor_through_the_fast_kernels(gpu, cpuref, monkeypatch, m):
+    """m = 2^e * odd with e >= 5: the innermost tensor factor CRT_{2^e} runs through the m = 2^k
+    kernels on contiguous blocks, the odd primes through the stage program.  Both routes (and
+    the all-stage-program route) against the oracle, every arithmetic class, ragged batch."""
+    pps = lm.factor_pps(m)
+    for qs in ([lm.first_good_q(m, 2 ** 20)], [lm.first_good_q(m, 2 ** 29), lm.first_good_q(m, 2 ** 31)],
+               [lm.first_good_q(m, 2 ** 60), lm.first_good_q(m, 2 ** 61)]):
+        R = Params(pps, qs)
+        rng = np.random.default_rng(m + len(qs))
+        y, z = R.random(rng, 5), R.random(rng, 5)
+        want = cpuref.crt(R, y), cpuref.crtinv(R, y), cpuref.polymul(R, y, z)
+        for route in ("split", "stages"):
+            if route == "stages":
+                monkeypatch.setenv("LOLHIP_NO_POW2_PART", "1")
+            P = gpu.Plan(pps, qs)
+            assert np.array_equal(P.crt(y), want[0]), (m, qs, route)
+            assert np.array_equal(P.crtInv(y), want[1]), (m, qs, route)
+            assert np.array_equal(P.polymul(y, z), want[2]), (m, qs, route)
+            monkeypatch.delenv("LOLHIP_NO_POW2_PART", raising=False)
+
+
 @pytest.mark.parametrize("m,q", BENCH1)
 def test_reference_benchmark_parameters(gpu, cpuref, m, q):
     """lol/Crypto/Lol/Benchmarks/Default.hs:42-46"""
