@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 #include "zq_dev.h"
@@ -50,6 +51,11 @@ constexpr int R = 4;
 constexpr int E = 1 << R;
 #ifndef LOLHIP_HALF_LEVELS
 #define LOLHIP_HALF_LEVELS 1
+#endif
+// levels whose eight twiddles are all distinct are fetched and consumed in this many parts
+// (2 or 4) in the register-lean schedule: 16 or 8 twiddle VGPRs live instead of 32
+#ifndef LOLHIP_LEVEL_PARTS
+#define LOLHIP_LEVEL_PARTS 4
 #endif
 #ifndef LOLHIP_PAIRED
 #define LOLHIP_PAIRED 0   // measured: hand-interleaving two butterflies is 5% SLOWER (more live VGPRs); kept for A/B
@@ -370,7 +376,7 @@ __device__ __forceinline__ void tw_fetch(LevelTwT<V>& t, const TwCtxT<V>& tw, in
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
-    if (level_tab<A, K>.slot[e] == ord && (HALF < 0 || (ord >> 2) == HALF)) {
+    if (level_tab<A, K>.slot[e] == ord && (HALF < 0 || ord / (8 / LOLHIP_LEVEL_PARTS) == HALF)) {
       const int cidx = level_tab<A, K>.cidx[e];
       if constexpr (tw_uniform<A, K>()) {
         t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
@@ -427,7 +433,7 @@ __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t,
   for (int e = 0; e < E; ++e) {
     if (e & (1 << K)) continue;
     ++ordb;
-    if (HALF >= 0 && (ordb >> 2) != HALF) continue;
+    if (HALF >= 0 && ordb / (8 / LOLHIP_LEVEL_PARTS) != HALF) continue;
     const int s = level_tab<A, K>.slot[e];
     if constexpr (!INV) bfly_fwd<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
     else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
@@ -563,9 +569,10 @@ template <int AR, bool INV, Lay A, int K>
 __device__ __forceinline__ void level_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
   using LevelTw = LevelTwT<VT<AR>>;
   if constexpr (LOLHIP_HALF_LEVELS && tw_distinct(A, K) == 8 && sizeof(VT<AR>) == 8) {
-    // all eight twiddles distinct (32 VGPRs): two halves of four keep the live set small
-    { LevelTw t; tw_fetch<INV, A, K, 0>(t, tw, xt); level<AR, INV, A, K, 0>(v, t, tw, qk); }
-    { LevelTw t; tw_fetch<INV, A, K, 1>(t, tw, xt); level<AR, INV, A, K, 1>(v, t, tw, qk); }
+    // all eight twiddles distinct (32 VGPRs): LOLHIP_LEVEL_PARTS parts keep the live set small
+    [&]<int... PART>(std::integer_sequence<int, PART...>) {
+      (([&] { LevelTw t; tw_fetch<INV, A, K, PART>(t, tw, xt); level<AR, INV, A, K, PART>(v, t, tw, qk); }()), ...);
+    }(std::make_integer_sequence<int, LOLHIP_LEVEL_PARTS>{});
   } else {
     LevelTw t; tw_fetch<INV, A, K>(t, tw, xt); level<AR, INV, A, K>(v, t, tw, qk);
   }
