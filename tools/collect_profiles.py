@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/collect_profiles.py — condense gpurun_out/refresh/ (written by tools/refresh_profiles.sh on
-the GPU box) into the committed files under profiles/."""
+the GPU box) into the committed files under profiles/.  Delete the local gpurun_out/refresh/ before
+the gpurun call: results are merged into it, and stale files from an earlier run would be averaged in."""
 import csv, glob, json, os, re, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +46,7 @@ traffic = {
     "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- tools/bench_kernels 14 1 4096 {crt,polymul} 5  (and --pmc WRITE_SIZE); tools/refresh_profiles.sh",
     "calibration_kernel": {"name": "k_pow2<13,0,1>", "known_read_KB": known_kb, "FETCH_SIZE_KB": f_crt[0], "factor": factor, "WRITE_SIZE_KB": w_crt[0]},
     "k_pow2_polymul": {"FETCH_SIZE_KB": f_pm[0], "WRITE_SIZE_KB": w_pm[0], "dispatches_averaged": f_pm[1], "read_bytes": int(read_b), "write_bytes": int(write_b),
-                       "note": "includes the register-spill scratch of the 64-bit fused kernel (write-back through L2)"},
+                       "note": "includes the register-spill scratch of the 64-bit fused kernel (one VGPR pair per thread, write-back through L2)"},
     "k_pow2_polymul_hbm_bytes_per_launch": int(read_b + write_b),
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": round((read_b + write_b) / alg, 4),
