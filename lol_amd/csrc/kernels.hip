@@ -755,7 +755,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
   else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
 
-  if constexpr (PPW == 1) {           // one polynomial per workgroup: make that provable to hipcc
+  if constexpr (NT >= 64) {           // a wave never straddles two polynomials: make that provable to hipcc
     t = __builtin_amdgcn_readfirstlane(t);
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
@@ -960,7 +960,7 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   i64 b, b0; int s;
   if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); s = r >> 3; b0 = b; }
   else { b = item / T; s = (int)(item % T); b0 = item0 / T; }
-  if constexpr (PPW == 1) {
+  if constexpr (NT >= 64) {
     s = __builtin_amdgcn_readfirstlane(s);
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
