@@ -935,7 +935,8 @@ hipError_t launch_pow2(const Pow2Launch& a, int mode) {
 // target component (L2 hits after the first), the addends once, and writes the two outputs
 // once: 5 slab passes.  One workgroup item = (ciphertext b, target component s); the digit
 // loop is a run-time loop around one register-resident forward transform; the two
-// accumulators (32 VGPRs) stay in registers in the transform's output layout.
+// accumulators (64-bit sums of raw products, 64 VGPRs) stay in registers in the transform's
+// output layout.
 // =============================================================================
 template <int L>
 __global__ void __launch_bounds__(pow2_threads(L), 4)
@@ -998,9 +999,16 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   const u32 off_h = (u32)s * 8u + (u32)xthr<LFIN>(tau) * uT8;             // hint polynomials (no batch axis)
   const u32 hstride = (u32)n * uT8;                                       // bytes per hint polynomial
 
-  V acc0[E], acc1[E];
+  // 64-bit accumulators of raw products: digit-hat < q and hint < q, so 16 products of < 2^60
+  // fit before a reduction is due — one multiply-add per (digit, hint coefficient) instead of a
+  // modular product
+  u64 acc0[E], acc1[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) { acc0[e] = 0; acc1[e] = 0; }
+  auto fold = [&](u64 x) -> u64 {                       // x mod q, any 64-bit x
+    const u64 r = x - __umul64hi(x, ms.mu) * ms.q;     // [0, 2q)
+    return (u64)csub32((u32)r, qk.q);
+  };
   const int shift = (int)(dp.base / 2);
   const u32 base = (u32)dp.base;
   int j = 0;
@@ -1047,15 +1055,20 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
         const u32 eo = (u32)lay_tab<LFIN>.xr[e] * uT8;
         const u32 h0 = (u32)load_u64(rh, off_h, hoff + eo);
         const u32 h1 = (u32)load_u64(rh, off_h, hoff + hstride + eo);
-        acc0[e] = csub32(acc0[e] + pmul<AR>(h0, v[e], ms, qk), qk.q);
-        acc1[e] = csub32(acc1[e] + pmul<AR>(h1, v[e], ms, qk), qk.q);
+        const u32 vc = canon_fwd<AR>(v[e], qk);                        // [0,4q) -> [0,q)
+        acc0[e] += (u64)h0 * vc;
+        acc1[e] += (u64)h1 * vc;
+      }
+      if ((j & 15) == 15) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { acc0[e] = fold(acc0[e]); acc1[e] = fold(acc1[e]); }
       }
     }
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const u32 eo = (u32)lay_tab<LFIN>.xr[e] * uT8;
-    u32 r0 = acc0[e], r1 = acc1[e];
+    u32 r0 = (u32)fold(acc0[e]), r1 = (u32)fold(acc1[e]);
     if (addend) {
       r0 = csub32(r0 + from_i64<AR>((i64)load_u64(ra0, off_fin, eo), qk), qk.q);
       r1 = csub32(r1 + from_i64<AR>((i64)load_u64(ra1, off_fin, eo), qk), qk.q);
