@@ -15,6 +15,7 @@
 // Layout at the boundary is the reference's: y[(b*n + j)*T + t] (tensor.h:69).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -1389,7 +1390,7 @@ __host__ __device__ constexpr bool vec_len_ok(int d) {
 }
 
 template <bool Q32>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_generic_vec(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
               const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw, i64 ngroups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1453,11 +1454,15 @@ hipError_t launch_generic(const GenericLaunch& a) {
     const i64 ngroups = (a.B + ppw - 1) / ppw;
     grid = ngroups * a.T;
     if (grid > 65536) grid = 65536;
+    // measured at m = 15015 / 1728 / 14336: 46 KiB polynomials want 512 threads (three groups per
+    // CU = 6 waves/SIMD), 1-2 K coefficient groups 128
+    const size_t coeffs = (size_t)ppw * a.n;
+    const int vthreads = coeffs >= 4096 ? 512 : (coeffs >= 2048 ? 256 : 128);
     if (a.q32)
-      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(256), lds_bytes, a.stream, a.y, a.B, a.T,
+      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y, a.B, a.T,
                          (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
     else
-      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(256), lds_bytes, a.stream, a.y, a.B, a.T,
+      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y, a.B, a.T,
                          (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
     return hipGetLastError();
   }
