@@ -65,9 +65,9 @@ int need_device(const lolhip_plan* p) {
   return LOLHIP_OK;
 }
 
-int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, int64_t B) {
+int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, int64_t B, const int64_t* src = nullptr) {
   GenericLaunch a;
-  a.stream = s; a.y = y; a.B = B; a.T = P.T; a.n = P.n;
+  a.stream = s; a.y = y; a.src = src; a.B = B; a.T = P.T; a.n = P.n;
   a.stages = sp.d_stages; a.nstages = sp.nstages;
   a.consts = P.d_consts; a.cpc = P.consts_per_comp; a.mod = P.d_mod;
   a.scratch = P.d_scratch; a.scratch_bytes = P.scratch_bytes;
@@ -78,6 +78,10 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
       a.vec_ok = false;
   a.q32 = true;
   for (u64 q : P.qs) if (q >= ((u64)1 << 32)) a.q32 = false;
+  if (src && !(a.vec_ok && (size_t)a.n * sizeof(u64) <= 64 * 1024)) {     // scalar interpreter: in place only
+    if (hipMemcpyAsync(y, src, sizeof(int64_t) * (size_t)(B * P.n * P.T), hipMemcpyDeviceToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
+    a.src = nullptr;
+  }
   return launch_generic(a) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
@@ -209,10 +213,16 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   }
   int64_t* tmp = P.d_tmp;
   rc = LOLHIP_OK;
-  if (hipMemcpyAsync(tmp, b, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
-  if (!rc && c != a && hipMemcpyAsync(c, a, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
-  if (!rc) rc = do_crt(P, s, c, B, false);
-  if (!rc) rc = do_crt(P, s, tmp, B, false);
+  if (!P.pow2_part || getenv("LOLHIP_NO_POW2_PART")) {
+    // stage program alone: transform b into the temp first (c may alias b), then a into c
+    rc = run_prog(P, P.prog_crt, s, tmp, B, b);
+    if (!rc) rc = run_prog(P, P.prog_crt, s, c, B, c != a ? a : nullptr);
+  } else {
+    if (hipMemcpyAsync(tmp, b, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
+    if (!rc && c != a && hipMemcpyAsync(c, a, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
+    if (!rc) rc = do_crt(P, s, c, B, false);
+    if (!rc) rc = do_crt(P, s, tmp, B, false);
+  }
   if (!rc) rc = lolhip_mul_batch(p, stream, c, tmp, B);
   if (!rc) rc = do_crt(P, s, c, B, true);
   return rc;

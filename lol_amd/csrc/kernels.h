@@ -44,6 +44,7 @@ hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a);
 struct GenericLaunch {
   hipStream_t stream;
   i64* y;
+  const i64* src;    // when non-null and the vector interpreter applies: read from here, write to y
   i64 B;
   int T;
   i64 n;

@@ -1391,7 +1391,7 @@ __host__ __device__ constexpr bool vec_len_ok(int d) {
 
 template <bool Q32>
 __global__ void __launch_bounds__(512)
-k_generic_vec(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
+k_generic_vec(i64* y, const i64* src, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
               const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw, i64 ngroups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* buf = reinterpret_cast<u64*>(smem);
@@ -1405,7 +1405,7 @@ k_generic_vec(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict_
     const int tot = np * n;
     const ModCtx mc = mod[t];
     const u64* cst = consts + (size_t)t * cpc;
-    for (int x = threadIdx.x; x < tot; x += blockDim.x) buf[x] = canon_in(y[((size_t)b0 * n + x) * T + t], mc.q);
+    for (int x = threadIdx.x; x < tot; x += blockDim.x) buf[x] = canon_in(src[((size_t)b0 * n + x) * T + t], mc.q);
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
       const Stage st = stages[s];
@@ -1459,11 +1459,11 @@ hipError_t launch_generic(const GenericLaunch& a) {
     const size_t coeffs = (size_t)ppw * a.n;
     const int vthreads = coeffs >= 4096 ? 512 : (coeffs >= 2048 ? 256 : 128);
     if (a.q32)
-      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y, a.B, a.T,
-                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
+      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y,
+                         a.src ? a.src : a.y, a.B, a.T, (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
     else
-      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y, a.B, a.T,
-                         (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
+      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y,
+                         a.src ? a.src : a.y, a.B, a.T, (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
     return hipGetLastError();
   }
   if (per_poly <= lds_budget) {

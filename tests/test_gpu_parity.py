@@ -402,7 +402,7 @@ def test_large_generic_polynomial_uses_scratch_path(gpu, cpuref):
 
 def test_device_tensors_and_aliasing(gpu, cpuref):
     torch = pytest.importorskip("torch")
-    for m in (2 ** 12, 2 ** 14, 45):
+    for m in (2 ** 12, 2 ** 14, 45, 96, 89):      # fused kernel x2, vector interpreter, 2-power split, scalar interpreter
         pps = lm.factor_pps(m)
         g = lm.good_qs(m, 2 ** 58)
         qs = [next(g), next(g)]
