@@ -50,16 +50,10 @@ namespace lolhip {
 
 constexpr int R = 4;
 constexpr int E = 1 << R;
-#ifndef LOLHIP_HALF_LEVELS
-#define LOLHIP_HALF_LEVELS 1
-#endif
 // levels whose eight twiddles are all distinct are fetched and consumed in this many parts
 // (2 or 4) in the register-lean schedule: 16 or 8 twiddle VGPRs live instead of 32
 #ifndef LOLHIP_LEVEL_PARTS
 #define LOLHIP_LEVEL_PARTS 4
-#endif
-#ifndef LOLHIP_PAIRED
-#define LOLHIP_PAIRED 0   // measured: hand-interleaving two butterflies is 5% SLOWER (more live VGPRs); kept for A/B
 #endif
 
 // Diagnostic build (-DLOLHIP_STAMPS): per-wave s_memtime stamps at phase boundaries, written
@@ -414,21 +408,6 @@ __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t,
   for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(t.w[s]), "v"(t.wp[s]));
   return;
 #endif
-#if LOLHIP_PAIRED
-  if constexpr (AR == 1 && !(INV && beta == 0)) {
-    // the 8 butterflies of a level, two at a time
-    constexpr int KP = (K == 0) ? 1 : 0;          // a register bit other than K: pairs e with e | 1<<KP
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      if ((e & (1 << K)) || (e & (1 << KP))) continue;
-      const int f = e | (1 << KP);
-      const int s1 = level_tab<A, K>.slot[e], s2 = level_tab<A, K>.slot[f];
-      if constexpr (!INV) bfly_fwd2(v[e], v[e | (1 << K)], t.w[s1], t.wp[s1], v[f], v[f | (1 << K)], t.w[s2], t.wp[s2], qk);
-      else bfly_inv2(v[e], v[e | (1 << K)], t.w[s1], t.wp[s1], v[f], v[f | (1 << K)], t.w[s2], t.wp[s2], qk);
-    }
-    return;
-  }
-#endif
   int ordb = -1;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -488,9 +467,6 @@ __device__ __forceinline__ void transpose_put(V (&v)[E], V* lds, int tau) {
   return;
 #endif
   if constexpr (!lay_eq(A, B)) {
-#ifdef LOLHIP_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     V* wp = lds + lpad(xthr<A>(tau));
 #pragma unroll
@@ -507,9 +483,6 @@ __device__ __forceinline__ void transpose_get(V (&v)[E], V* lds, int tau) {
     const V* rp = lds + lpad(xthr<B>(tau));
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = rp[lpad(lay_tab<B>.xr[e])];
-#ifdef LOLHIP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   }
 }
 
@@ -569,7 +542,7 @@ __device__ __forceinline__ void fetch4(LevelTwT<VT<AR>> (&t)[R], const TwCtxT<VT
 template <int AR, bool INV, Lay A, int K>
 __device__ __forceinline__ void level_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
   using LevelTw = LevelTwT<VT<AR>>;
-  if constexpr (LOLHIP_HALF_LEVELS && tw_distinct(A, K) == 8 && sizeof(VT<AR>) == 8) {
+  if constexpr (tw_distinct(A, K) == 8 && sizeof(VT<AR>) == 8) {
     // all eight twiddles distinct (32 VGPRs): LOLHIP_LEVEL_PARTS parts keep the live set small
     [&]<int... PART>(std::integer_sequence<int, PART...>) {
       (([&] { LevelTw t; tw_fetch<INV, A, K, PART>(t, tw, xt); level<AR, INV, A, K, PART>(v, t, tw, qk); }()), ...);

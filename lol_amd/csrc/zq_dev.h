@@ -87,11 +87,7 @@ LH_D u64 shoup_lazy(u64 y, u64 w, u64 wp, u64 q) {
 #define LOLHIP_ASM_MAD 3
 #endif
 LH_D u64 mad64(u32 a, u32 b, u64 c) {
-#if LOLHIP_ASM_MAD == 2
-  u64 d;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-  return d;
-#elif LOLHIP_ASM_MAD
+#if LOLHIP_ASM_MAD
   u64 d, carry;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
   return d;
@@ -205,51 +201,6 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
   asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
   return ((u64)th << 32) | lo32(t);
 #endif
-}
-
-// Two independent Shoup products with their instruction streams interleaved by hand: at
-// 4 waves/SIMD back-to-back dependent v_mad_u64_u32 leave issue slots empty; here every
-// instruction's producer is at least two instructions upstream.
-LH_D void shoup_acc2(u64 y1, u64 w1, u64 wp1, u64 init1, u64 y2, u64 w2, u64 wp2, u64 init2, u64 nq,
-                     u64& r1, u64& r2) {
-  u64 Q1, Q2, t1, t2, h1, h2;
-  u32 a1, b1, a2, b2;
-  asm("v_mul_hi_u32 %2, %6, %8\n\t"
-      "v_mul_hi_u32 %4, %10, %12\n\t"
-      "v_mul_hi_u32 %3, %7, %9\n\t"
-      "v_mul_hi_u32 %5, %11, %13\n\t"
-      "v_mad_u64_u32 %0, vcc, %6, %9, 0\n\t"
-      "v_mad_u64_u32 %1, vcc, %10, %13, 0\n\t"
-      "v_mad_u64_u32 %0, vcc, %2, 1, %0\n\t"
-      "v_mad_u64_u32 %1, vcc, %4, 1, %1\n\t"
-      "v_mad_u64_u32 %0, vcc, %3, 1, %0\n\t"
-      "v_mad_u64_u32 %1, vcc, %5, 1, %1"
-      : "=&v"(Q1), "=&v"(Q2), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2)
-      : "v"(hi32(wp1)), "v"(lo32(wp1)), "v"(lo32(y1)), "v"(hi32(y1)),
-        "v"(hi32(wp2)), "v"(lo32(wp2)), "v"(lo32(y2)), "v"(hi32(y2))
-      : "vcc");
-  asm("v_mad_u64_u32 %0, vcc, %4, %6, %10\n\t"      // t1 = w1.lo*y1.lo + init1
-      "v_mad_u64_u32 %1, vcc, %11, %13, %17\n\t"    // t2
-      "v_mad_u64_u32 %2, vcc, %4, %7, 0\n\t"        // h1 = w1.lo*y1.hi
-      "v_mad_u64_u32 %3, vcc, %11, %14, 0\n\t"      // h2
-      "v_mad_u64_u32 %0, vcc, %8, %18, %0\n\t"      // t1 += Q1.lo*nq.lo
-      "v_mad_u64_u32 %1, vcc, %15, %18, %1\n\t"
-      "v_mad_u64_u32 %2, vcc, %5, %6, %2\n\t"       // h1 += w1.hi*y1.lo
-      "v_mad_u64_u32 %3, vcc, %12, %13, %3\n\t"
-      "v_mad_u64_u32 %2, vcc, %8, %19, %2\n\t"      // h1 += Q1.lo*nq.hi
-      "v_mad_u64_u32 %3, vcc, %15, %19, %3\n\t"
-      "v_mad_u64_u32 %2, vcc, %9, %18, %2\n\t"      // h1 += Q1.hi*nq.lo
-      "v_mad_u64_u32 %3, vcc, %16, %18, %3"
-      : "=&v"(t1), "=&v"(t2), "=&v"(h1), "=&v"(h2)
-      : "v"(lo32(w1)), "v"(hi32(w1)), "v"(lo32(y1)), "v"(hi32(y1)), "v"(lo32(Q1)), "v"(hi32(Q1)), "v"(init1),
-        "v"(lo32(w2)), "v"(hi32(w2)), "v"(lo32(y2)), "v"(hi32(y2)), "v"(lo32(Q2)), "v"(hi32(Q2)), "v"(init2),
-        "v"(lo32(nq)), "v"(hi32(nq))
-      : "vcc");
-  u32 th1, th2;
-  asm("v_add_u32 %0, %1, %2" : "=v"(th1) : "v"(hi32(t1)), "v"(lo32(h1)));
-  asm("v_add_u32 %0, %1, %2" : "=v"(th2) : "v"(hi32(t2)), "v"(lo32(h2)));
-  r1 = ((u64)th1 << 32) | lo32(t1);
-  r2 = ((u64)th2 << 32) | lo32(t2);
 }
 
 // remainder of the 128-bit value (u1:u0) by c.q, requires (u1:u0) < q * 2^64
