@@ -228,6 +228,21 @@ enum {
 };
 LOLHIP_API int lolhip_ext_host(const lolhip_ext *x, int op, int64_t *out, const int64_t *in, int64_t B);
 
+/* --- wire format: Lol's protobuf ring elements, host side -------
+ * message Rq { uint32 m = 1; uint64 q = 2; repeated sint64 xs = 3; }   (lol/Lol.proto)
+ * message RqProduct { repeated Rq rqlist = 1; }
+ * One Rq per RNS modulus, first component first; xs are decoding-basis coefficients written
+ * as centred lifts (IZipVector.hs:127-205).  Ingest = read -> [n][T] slab -> l -> crt.
+ * read : returns n (coefficients per modulus); fills m, T, qs[T] and, when xs != NULL, the
+ *        reduced residues xs[j*T + t] in [0, q_t).  Pass xs = NULL to query sizes.
+ * write: returns the number of bytes (needed when out == NULL, written otherwise); xs as
+ *        above (any representative in (-q, q)).  Unpacked sint64 encoding (proto2 default);
+ *        the reader also accepts the packed form.  Negative return = LOLHIP_ERR_*. */
+LOLHIP_API int64_t lolhip_rqproduct_read(const uint8_t *buf, int64_t len, uint32_t *m, int64_t *qs, int cap_T,
+                                         int *T, int64_t *xs, int64_t cap_xs);
+LOLHIP_API int64_t lolhip_rqproduct_write(uint32_t m, const int64_t *qs, int T, const int64_t *xs, int64_t n,
+                                          uint8_t *out, int64_t cap);
+
 /* number of HIP devices visible (0 without a GPU); never initialises a context */
 LOLHIP_API int lolhip_device_count(void);
 LOLHIP_API const char *lolhip_version(void);

@@ -1,0 +1,152 @@
+// lol_amd/csrc/wire.cpp — reader/writer for Lol's protobuf ring-element messages (host side).
+//
+// Messages (lol/Lol.proto, proto2):
+//   message Rq        { required uint32 m = 1; required uint64 q = 2; repeated sint64 xs = 3; }
+//   message RqProduct { repeated Rq rqlist = 1; }
+// Conventions (lol/Crypto/Lol/Types/IZipVector.hs:127-205, Lol.proto:18-20): one Rq per
+// modulus of the RNS tuple, first component first; xs are the coefficients in the DECODING
+// basis, written as centred lifts in [-q/2, q/2) (toProto: `LP.lift`), read back with `reduce`.
+// So ingest for the GPU path is: read -> slab [n][T] -> lolhip_l_batch -> lolhip_crt_batch.
+//
+// The codec is written against the protobuf wire specification (varint, zigzag, length-
+// delimited sub-messages); it accepts both the unpacked encoding that proto2 `repeated sint64`
+// uses by default (what hprotoc emits) and the packed one.  Unknown fields are skipped.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "lolhip.h"
+
+namespace {
+
+struct Reader {
+  const uint8_t* p; const uint8_t* end; bool ok = true;
+  bool varint(uint64_t& v) {
+    v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (p >= end) return ok = false;
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return true;
+    }
+    return ok = false;
+  }
+  bool skip(uint32_t wt) {
+    uint64_t v;
+    switch (wt) {
+      case 0: return varint(v);
+      case 1: if (end - p < 8) return ok = false; p += 8; return true;
+      case 2: if (!varint(v) || (uint64_t)(end - p) < v) return ok = false; p += v; return true;
+      case 5: if (end - p < 4) return ok = false; p += 4; return true;
+      default: return ok = false;
+    }
+  }
+};
+
+inline int64_t unzigzag(uint64_t z) { return (int64_t)(z >> 1) ^ -(int64_t)(z & 1); }
+inline uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+
+inline int varint_len(uint64_t v) { int n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+inline void put_varint(uint8_t*& o, uint64_t v) { while (v >= 0x80) { *o++ = (uint8_t)(v | 0x80); v >>= 7; } *o++ = (uint8_t)v; }
+
+struct RqView { uint32_t m = 0; uint64_t q = 0; bool has_m = false, has_q = false; std::vector<int64_t> xs; };
+
+bool parse_rq(const uint8_t* b, const uint8_t* e, RqView& r) {
+  Reader rd{b, e};
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return false;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    uint64_t v;
+    if (field == 1 && wt == 0) { if (!rd.varint(v)) return false; r.m = (uint32_t)v; r.has_m = true; }
+    else if (field == 2 && wt == 0) { if (!rd.varint(v)) return false; r.q = v; r.has_q = true; }
+    else if (field == 3 && wt == 0) { if (!rd.varint(v)) return false; r.xs.push_back(unzigzag(v)); }
+    else if (field == 3 && wt == 2) {                      // packed
+      if (!rd.varint(v) || (uint64_t)(rd.end - rd.p) < v) return false;
+      Reader in{rd.p, rd.p + v};
+      while (in.p < in.end) { uint64_t z; if (!in.varint(z)) return false; r.xs.push_back(unzigzag(z)); }
+      rd.p += v;
+    } else if (!rd.skip(wt)) return false;
+  }
+  return r.has_m && r.has_q;                                // both are `required`
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t lolhip_rqproduct_read(const uint8_t* buf, int64_t len, uint32_t* m_out, int64_t* qs, int cap_T, int* T_out,
+                              int64_t* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  std::vector<RqView> list;
+  Reader rd{buf, buf + len};
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 2) {
+      uint64_t l;
+      if (!rd.varint(l) || (uint64_t)(rd.end - rd.p) < l) return LOLHIP_ERR_INVALID;
+      list.emplace_back();
+      if (!parse_rq(rd.p, rd.p + l, list.back())) return LOLHIP_ERR_INVALID;
+      rd.p += l;
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  const int T = (int)list.size();
+  if (T == 0) return LOLHIP_ERR_INVALID;
+  const int64_t n = (int64_t)list[0].xs.size();
+  for (const RqView& r : list) {
+    if (r.m != list[0].m || (int64_t)r.xs.size() != n) return LOLHIP_ERR_INVALID;   // one ring, one length
+    if (r.q < 2 || r.q >= ((uint64_t)1 << 62)) return LOLHIP_ERR_MODULUS;
+  }
+  if (m_out) *m_out = list[0].m;
+  if (T_out) *T_out = T;
+  if (qs) {
+    if (cap_T < T) return LOLHIP_ERR_INVALID;
+    for (int t = 0; t < T; ++t) qs[t] = (int64_t)list[(size_t)t].q;
+  }
+  if (xs) {
+    if (cap_xs < n * T) return LOLHIP_ERR_INVALID;
+    for (int t = 0; t < T; ++t) {
+      const int64_t q = (int64_t)list[(size_t)t].q;
+      for (int64_t j = 0; j < n; ++j) {                     // `reduce`: canonical residue of any integer
+        int64_t r = list[(size_t)t].xs[(size_t)j] % q;
+        xs[j * T + t] = r < 0 ? r + q : r;
+      }
+    }
+  }
+  return n;
+}
+
+int64_t lolhip_rqproduct_write(uint32_t m, const int64_t* qs, int T, const int64_t* xs, int64_t n, uint8_t* out,
+                               int64_t cap) {
+  if (!qs || T < 1 || n < 0 || (n > 0 && !xs)) return LOLHIP_ERR_INVALID;
+  for (int t = 0; t < T; ++t) if (qs[t] < 2) return LOLHIP_ERR_MODULUS;
+  // centred lift of component t of coefficient j (ZqBasic.hs:92-94), accepting (-q, q) inputs
+  auto lifted = [&](int64_t j, int t) {
+    const int64_t q = qs[t];
+    int64_t x = xs[j * T + t] % q;
+    if (x < 0) x += q;
+    return (x < q - x) ? x : x - q;                         // 2x < q  without overflow
+  };
+  std::vector<int64_t> body((size_t)T);
+  int64_t total = 0;
+  for (int t = 0; t < T; ++t) {
+    int64_t b = 1 + varint_len(m) + 1 + varint_len((uint64_t)qs[t]);
+    for (int64_t j = 0; j < n; ++j) b += 1 + varint_len(zigzag(lifted(j, t)));
+    body[(size_t)t] = b;
+    total += 1 + varint_len((uint64_t)b) + b;
+  }
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  for (int t = 0; t < T; ++t) {
+    *o++ = 0x0A; put_varint(o, (uint64_t)body[(size_t)t]);  // rqlist = 1, length-delimited
+    *o++ = 0x08; put_varint(o, m);                          // m = 1
+    *o++ = 0x10; put_varint(o, (uint64_t)qs[t]);            // q = 2
+    for (int64_t j = 0; j < n; ++j) { *o++ = 0x18; put_varint(o, zigzag(lifted(j, t))); }   // xs = 3, unpacked sint64
+  }
+  return (int64_t)(o - out);
+}
+
+}  // extern "C"

@@ -110,6 +110,11 @@ def lib():
     L.lolhip_ext_table.restype = i64
     L.lolhip_op_host.argtypes = [vp, ci, _i64p, _i64p, i64]
     L.lolhip_ext_host.argtypes = [vp, ci, _i64p, _i64p, i64]
+    u8p = C.POINTER(C.c_uint8)
+    L.lolhip_rqproduct_read.argtypes = [u8p, i64, C.POINTER(C.c_uint32), _i64p, ci, C.POINTER(ci), _i64p, i64]
+    L.lolhip_rqproduct_read.restype = i64
+    L.lolhip_rqproduct_write.argtypes = [C.c_uint32, _i64p, ci, _i64p, i64, u8p, i64]
+    L.lolhip_rqproduct_write.restype = i64
     L.lolhip_device_count.restype = ci
     L.lolhip_version.restype = C.c_char_p
     L.lolhip_last_status.restype = ci
@@ -147,6 +152,37 @@ def factor_pps(m: int):
             out.append((m, 1))
             break
     return out
+
+
+def rqproduct_write(m: int, qs, xs) -> bytes:
+    """Serialise decoding-basis residues xs [n][T] as a Lol `RqProduct` message (lol/Lol.proto;
+    IZipVector.hs:127-205): one Rq per modulus, centred lifts, unpacked sint64."""
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    qa = np.ascontiguousarray(qs, dtype=np.int64)
+    T = len(qa)
+    n = xs.size // max(T, 1)
+    L = lib()
+    need = L.lolhip_rqproduct_write(m, qa.ctypes.data_as(_i64p), T, xs.ctypes.data_as(_i64p), n, None, 0)
+    _check(min(need, 0))
+    buf = (C.c_uint8 * max(need, 1))()
+    wrote = L.lolhip_rqproduct_write(m, qa.ctypes.data_as(_i64p), T, xs.ctypes.data_as(_i64p), n, buf, need)
+    _check(min(wrote, 0))
+    return bytes(buf[:wrote])
+
+
+def rqproduct_read(data: bytes):
+    """Parse a Lol `RqProduct` message -> (m, [q_t], xs [n][T]) with canonical residues."""
+    L = lib()
+    raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    m, T = C.c_uint32(0), C.c_int(0)
+    qs = np.zeros(16, dtype=np.int64)
+    n = L.lolhip_rqproduct_read(raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T), None, 0)
+    _check(min(n, 0))
+    xs = np.zeros((n, T.value), dtype=np.int64)
+    n2 = L.lolhip_rqproduct_read(raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T),
+                                 xs.ctypes.data_as(_i64p), xs.size)
+    _check(min(n2, 0))
+    return int(m.value), [int(q) for q in qs[:T.value]], xs
 
 
 def _np(a):

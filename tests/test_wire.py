@@ -1,0 +1,107 @@
+"""Lol's protobuf ring-element messages (lol/Lol.proto: Rq, RqProduct; conventions of
+lol/Crypto/Lol/Types/IZipVector.hs:127-205) — SURVEY.md §8f N3.
+
+The reference ships no serialized samples, so the codec in liblolhip (written against the
+wire specification) is pinned against google.protobuf itself: the same two messages are
+declared through a dynamic descriptor, and bytes produced by either side must parse on the
+other — for the unpacked encoding hprotoc emits and for the packed one.  Plus the Lol
+conventions: centred lifts on write, `reduce` on read, one Rq per modulus in tuple order.
+"""
+import numpy as np
+import pytest
+
+from oracle import lolmath as lm
+from oracle.oracle import Params
+
+
+def _messages():
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="lol_wire_test.proto", package="crypto.proto.lol", syntax="proto2")
+    F = descriptor_pb2.FieldDescriptorProto
+    rq = fd.message_type.add(name="Rq")
+    rq.field.add(name="m", number=1, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    rq.field.add(name="q", number=2, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
+    rq.field.add(name="xs", number=3, type=F.TYPE_SINT64, label=F.LABEL_REPEATED)
+    rqp = fd.message_type.add(name="RqPacked")                      # same message, packed xs
+    rqp.field.add(name="m", number=1, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    rqp.field.add(name="q", number=2, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
+    f = rqp.field.add(name="xs", number=3, type=F.TYPE_SINT64, label=F.LABEL_REPEATED)
+    f.options.packed = True
+    prod = fd.message_type.add(name="RqProduct")
+    prod.field.add(name="rqlist", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.Rq")
+    prodp = fd.message_type.add(name="RqProductPacked")
+    prodp.field.add(name="rqlist", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqPacked")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    cls = (lambda n: get(pool.FindMessageTypeByName("crypto.proto.lol." + n))) if get else \
+          (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("crypto.proto.lol." + n)))
+    return cls("RqProduct"), cls("RqProductPacked")
+
+
+def _lift(x, q):
+    x = int(x) % q
+    return x if 2 * x < q else x - q
+
+
+CASES = [(8, [17]), (1024, [12289]), (21, [8191, lm.first_good_q(21, 2 ** 30)]),
+         (16, [lm.first_good_q(16, 2 ** 60), 97, lm.first_good_q(16, 2 ** 61)])]
+
+
+@pytest.mark.parametrize("m,qs", CASES)
+def test_rqproduct_against_google_protobuf(m, qs):
+    import lol_amd
+    RqProduct, RqProductPacked = _messages()
+    R = Params(lm.factor_pps(m), qs)
+    rng = np.random.default_rng(m)
+    xs = R.random(rng, 1)[0]                                    # [n][T]
+    xs[0], xs[1 % R.n] = 0, np.array(qs) - 1
+    xs[2 % R.n] = np.array(qs) // 2
+    # ours -> protobuf
+    data = lol_amd.rqproduct_write(m, qs, xs)
+    msg = RqProduct()
+    msg.ParseFromString(data)
+    assert len(msg.rqlist) == len(qs)
+    for t, rq in enumerate(msg.rqlist):
+        assert rq.m == m and rq.q == qs[t]
+        assert list(rq.xs) == [_lift(v, qs[t]) for v in xs[:, t]]              # centred lifts (toProto)
+    assert msg.SerializeToString() == data                                      # byte-identical encoding
+    # protobuf -> ours, unpacked and packed, with unreduced / negative representatives
+    for cls in (RqProduct, RqProductPacked):
+        msg = cls()
+        for t, q in enumerate(qs):
+            rq = msg.rqlist.add()
+            rq.m, rq.q = m, q
+            rq.xs.extend(int(v) - (q if i % 3 == 0 and v else 0) for i, v in enumerate(xs[:, t]))
+        m2, qs2, xs2 = lol_amd.rqproduct_read(msg.SerializeToString())
+        assert (m2, qs2) == (m, list(qs)) and np.array_equal(xs2, xs)           # `reduce` on read (fromProto)
+    # round trip through ourselves, (-q, 0] inputs
+    neg = np.where(xs > 0, xs - np.array(qs), 0)
+    assert lol_amd.rqproduct_read(lol_amd.rqproduct_write(m, qs, neg))[2].tolist() == xs.tolist()
+
+
+def test_rqproduct_rejects_malformed_input():
+    import lol_amd
+    good = lol_amd.rqproduct_write(8, [17, 97], np.arange(8).reshape(4, 2))
+    for bad in (b"", good[:-1], good[:5], b"\x0a\x7f" + good, good + b"\x0a\x02\x08\x09"):   # truncated / m differs / no q
+        with pytest.raises(lol_amd.LolHipError):
+            lol_amd.rqproduct_read(bad)
+    with pytest.raises(lol_amd.LolHipError):
+        lol_amd.rqproduct_write(8, [1], np.zeros((4, 1)))
+
+
+@pytest.mark.gpu
+def test_ingest_rqproduct_to_crt_basis(gpu, cpuref):
+    """serialized decoding-basis element -> slab -> l -> crt on the card = oracle of the same."""
+    import lol_amd
+    m = 2 ** 8 * 3
+    qs = [lm.first_good_q(m, 2 ** 20), lm.first_good_q(m, 2 ** 59)]
+    pps = lm.factor_pps(m)
+    P, R = gpu.Plan(pps, qs), Params(pps, qs)
+    rng = np.random.default_rng(7)
+    dec = R.random(rng, 3)
+    blobs = [lol_amd.rqproduct_write(m, qs, d) for d in dec]
+    slab = np.stack([lol_amd.rqproduct_read(b)[2] for b in blobs])
+    assert np.array_equal(slab, dec)
+    assert np.array_equal(P.crt(P.l(slab)), cpuref.crt(R, cpuref.l(R, dec)))
