@@ -3,6 +3,7 @@
 # HBM-traffic counters in separate passes, pipeline bench.  Everything lands in gpurun_out/;
 # tools/collect_profiles.py then condenses it into profiles/.
 set -e
+# needs tools/bench_kernels (make -C tools bench_kernels; the binary travels with the gpurun snapshot)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
