@@ -96,6 +96,34 @@ def cpu_baseline(q: int, budget_s: float = 12.0):
     }
 
 
+def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
+    """Not the metric: the same launch shape in the other regimes, for context (N = 1 only).
+    ms per launch from HIP events; GB/s = algorithmic bytes / time."""
+    def timed(fn, iters=10):
+        fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for s_, e_ in ev:
+            s_.record(stream); fn(); e_.record(stream)
+        torch.cuda.synchronize()
+        return sum(s_.elapsed_time(e_) for s_, e_ in ev) / iters
+    slab = B * n * T * 8
+    out = {}
+    c.copy_(a)
+    ms = timed(lambda: plan.crt(c, stream=stream.cuda_stream))
+    out["crt_61bit"] = {"ms": round(ms, 4), "GBps": round(2 * slab / ms / 1e6, 1)}
+    q30 = lol_amd.good_q(M_INDEX, 1 << 29)
+    p30 = lol_amd.Plan([(2, 14)], [q30])
+    x = a % q30
+    y = torch.empty_like(x)
+    x2 = (a + 1) % q30
+    ms = timed(lambda: p30.polymul(x, x2, out=y, stream=stream.cuda_stream))
+    out["polymul_30bit"] = {"ms": round(ms, 4), "poly_muls_per_s": round(B / ms * 1e3, 1), "GBps": round(3 * slab / ms / 1e6, 1), "q": q30}
+    y.copy_(x)
+    ms = timed(lambda: p30.crt(y, stream=stream.cuda_stream))
+    out["crt_30bit"] = {"ms": round(ms, 4), "GBps": round(2 * slab / ms / 1e6, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +230,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_sample_ok": parity,
         }
+        if n_gpus == 1:
+            out["secondary"] = secondary(lol_amd, torch, plan, a, c, B, n, T, stream)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(q)
         print(json.dumps(out, ensure_ascii=False), flush=True)
