@@ -702,7 +702,10 @@ __device__ __forceinline__ void inv_transform(VT<AR> (&v)[E], VT<AR>* lds, const
 constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
 
 // MODE 0: crt in place, 1: crtInv in place, 2: c = crtInv(crt(a) * crt(b))
-template <int L, int MODE, int AR>
+// TU ("T uniform"): the launch has a single modulus, so t = 0 for every lane even when a wave
+// holds several short polynomials — the per-modulus constants stay in SGPRs (instantiated for
+// n <= 512 only; longer polynomials own whole waves and are uniform anyway)
+template <int L, int MODE, int AR, bool TU = false>
 __global__ void __launch_bounds__(pow2_threads(L), AR == 2 ? 8 : 4)
 k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
        const VT<AR>* __restrict__ tw_fwd, const VT<AR>* __restrict__ tw_inv, const VT<AR>* __restrict__ scale,
@@ -728,6 +731,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   i64 b, b0; int t;
   if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
   else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
+  if constexpr (TU) { b = item; t = 0; b0 = item0; }
 
   if constexpr (NT >= 64) {           // a wave never straddles two polynomials: make that provable to hipcc
     t = __builtin_amdgcn_readfirstlane(t);
@@ -851,6 +855,14 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
+  }
+  if constexpr (NT < 64 && AR != 2) {
+    if (a.T == 1) {
+      hipLaunchKernelGGL((k_pow2<L, MODE, AR, true>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
+                         a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
+                         static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
+      return hipGetLastError();
+    }
   }
   hipLaunchKernelGGL((k_pow2<L, MODE, AR>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
                      a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
