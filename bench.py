@@ -13,7 +13,7 @@ so scaling is weak: each rank multiplies its own 4096-polynomial shard.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` is algorithmic bytes
 (3 * n * T * 8 per poly-mul) over the mean launch duration measured with
-HIP events on the launch stream inside the timed region.
+HIP events on the launch stream inside the timed region (one pair around the K launches).
 """
 from __future__ import annotations
 
@@ -127,8 +127,8 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -167,15 +167,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one HIP-event pair on the launch stream around the K launches (they queue back to back;
+    # an event pair per launch would put a marker packet between every two kernels)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record(stream)
+    ev0.record(stream)
+    for _ in range(args.steps):
         step()
-        e.record(stream)
+    ev1.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -184,7 +186,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(1, len(ev))
+    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)
 
     # ---- correctness of what was timed: strided sample against the CPU oracle -----
     parity = None

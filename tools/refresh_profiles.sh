@@ -8,9 +8,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+python3 $R/bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err
 echo "kernel trace done"
 for op in crt polymul; do
   for c in FETCH_SIZE WRITE_SIZE; do
