@@ -243,6 +243,14 @@ LOLHIP_API int64_t lolhip_rqproduct_read(const uint8_t *buf, int64_t len, uint32
 LOLHIP_API int64_t lolhip_rqproduct_write(uint32_t m, const int64_t *qs, int T, const int64_t *xs, int64_t n,
                                           uint8_t *out, int64_t cap);
 
+/* KSHint (lol-apps/SHE.proto: repeated RqPolynomial hint = 1; TypeRep gad = 2; RqPolynomial =
+ * repeated RqProduct coeffs, constant coefficient first): the L hint polynomials of K
+ * coefficients each -> xs [L][K][n][T], decoding basis, canonical residues; l and crt over the
+ * L*K polynomials then give the hint slab of lolhip_keyswitch_batch.  Returns n; xs = NULL
+ * queries L, K, T, m, qs.  The gadget fingerprint is skipped. */
+LOLHIP_API int64_t lolhip_kshint_read(const uint8_t *buf, int64_t len, uint32_t *m, int64_t *qs, int cap_T, int *T,
+                                      int *L, int *K, int64_t *xs, int64_t cap_xs);
+
 /* number of HIP devices visible (0 without a GPU); never initialises a context */
 LOLHIP_API int lolhip_device_count(void);
 LOLHIP_API const char *lolhip_version(void);

@@ -10,8 +10,8 @@ calls raise.
 """
 from .tensor import (  # noqa: F401
     LolHipError, NoDeviceError, Plan, Ext, lib, lib_path, device_count, good_q, factor_pps,
-    rqproduct_read, rqproduct_write,
+    rqproduct_read, rqproduct_write, kshint_read,
 )
 
 __all__ = ["LolHipError", "NoDeviceError", "Plan", "Ext", "lib", "lib_path", "device_count",
-           "good_q", "factor_pps", "rqproduct_read", "rqproduct_write"]
+           "good_q", "factor_pps", "rqproduct_read", "rqproduct_write", "kshint_read"]

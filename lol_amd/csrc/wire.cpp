@@ -149,4 +149,67 @@ int64_t lolhip_rqproduct_write(uint32_t m, const int64_t* qs, int T, const int64
   return (int64_t)(o - out);
 }
 
+// KSHint (lol-apps/SHE.proto): { repeated RqPolynomial hint = 1; required TypeRep gad = 2; }
+// RqPolynomial: { repeated RqProduct coeffs = 1; }  constant coefficient first.
+// Reads the L hint polynomials of K coefficients each into xs [L][K][n][T] (decoding basis,
+// canonical residues) — after l and crt over the L*K polynomials, the slab lolhip_keyswitch_batch
+// takes.  The gadget TypeRep (a GHC fingerprint, "not intended to be platform independent",
+// Lol.proto) is skipped.  Returns n; pass xs = NULL to query L, K, T, m, qs.
+int64_t lolhip_kshint_read(const uint8_t* buf, int64_t len, uint32_t* m_out, int64_t* qs, int cap_T, int* T_out,
+                           int* L_out, int* K_out, int64_t* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  struct Span { const uint8_t* p; int64_t n; };
+  std::vector<std::vector<Span>> polys;
+  Reader rd{buf, buf + len};
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 2) {
+      uint64_t l;
+      if (!rd.varint(l) || (uint64_t)(rd.end - rd.p) < l) return LOLHIP_ERR_INVALID;
+      polys.emplace_back();
+      Reader in{rd.p, rd.p + l};
+      while (in.p < in.end) {
+        uint64_t k2;
+        if (!in.varint(k2)) return LOLHIP_ERR_INVALID;
+        if ((k2 >> 3) == 1 && (k2 & 7) == 2) {
+          uint64_t l2;
+          if (!in.varint(l2) || (uint64_t)(in.end - in.p) < l2) return LOLHIP_ERR_INVALID;
+          polys.back().push_back(Span{in.p, (int64_t)l2});
+          in.p += l2;
+        } else if (!in.skip((uint32_t)(k2 & 7))) return LOLHIP_ERR_INVALID;
+      }
+      rd.p += l;
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  const int L = (int)polys.size();
+  if (L == 0) return LOLHIP_ERR_INVALID;
+  const int K = (int)polys[0].size();
+  if (K == 0) return LOLHIP_ERR_INVALID;
+  for (auto& pl : polys) if ((int)pl.size() != K) return LOLHIP_ERR_INVALID;
+  uint32_t m0 = 0; int T0 = 0;
+  std::vector<int64_t> q0(cap_T > 0 ? (size_t)cap_T : 16);
+  const int64_t n = lolhip_rqproduct_read(polys[0][0].p, polys[0][0].n, &m0, q0.data(), (int)q0.size(), &T0, nullptr, 0);
+  if (n < 0) return n;
+  if (m_out) *m_out = m0;
+  if (T_out) *T_out = T0;
+  if (L_out) *L_out = L;
+  if (K_out) *K_out = K;
+  if (qs) { if (cap_T < T0) return LOLHIP_ERR_INVALID; for (int t = 0; t < T0; ++t) qs[t] = q0[(size_t)t]; }
+  if (!xs) return n;
+  if (cap_xs < (int64_t)L * K * n * T0) return LOLHIP_ERR_INVALID;
+  std::vector<int64_t> q1(q0.size());
+  for (int j = 0; j < L; ++j)
+    for (int k = 0; k < K; ++k) {
+      uint32_t m1 = 0; int T1 = 0;
+      const int64_t n1 = lolhip_rqproduct_read(polys[(size_t)j][(size_t)k].p, polys[(size_t)j][(size_t)k].n, &m1, q1.data(),
+                                               (int)q1.size(), &T1, xs + ((int64_t)j * K + k) * n * T0, n * T0);
+      if (n1 < 0) return n1;
+      if (n1 != n || m1 != m0 || T1 != T0) return LOLHIP_ERR_INVALID;     // every entry over the same ring and moduli
+      for (int t = 0; t < T0; ++t) if (q1[(size_t)t] != q0[(size_t)t]) return LOLHIP_ERR_INVALID;
+    }
+  return n;
+}
+
 }  // extern "C"

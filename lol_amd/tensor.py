@@ -115,6 +115,8 @@ def lib():
     L.lolhip_rqproduct_read.restype = i64
     L.lolhip_rqproduct_write.argtypes = [C.c_uint32, _i64p, ci, _i64p, i64, u8p, i64]
     L.lolhip_rqproduct_write.restype = i64
+    L.lolhip_kshint_read.argtypes = [u8p, i64, C.POINTER(C.c_uint32), _i64p, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), _i64p, i64]
+    L.lolhip_kshint_read.restype = i64
     L.lolhip_device_count.restype = ci
     L.lolhip_version.restype = C.c_char_p
     L.lolhip_last_status.restype = ci
@@ -182,6 +184,21 @@ def rqproduct_read(data: bytes):
     n2 = L.lolhip_rqproduct_read(raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T),
                                  xs.ctypes.data_as(_i64p), xs.size)
     _check(min(n2, 0))
+    return int(m.value), [int(q) for q in qs[:T.value]], xs
+
+
+def kshint_read(data: bytes):
+    """Parse a SymmSHE `KSHint` message (lol-apps/SHE.proto) -> (m, [q_t], xs [L][K][n][T]),
+    decoding basis; `plan.crt(plan.l(xs.reshape(L*K, n, T)))` is the hint slab of keySwitch."""
+    L_ = lib()
+    raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    m, T, Lh, K = C.c_uint32(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    qs = np.zeros(16, dtype=np.int64)
+    args = (raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T), C.byref(Lh), C.byref(K))
+    n = L_.lolhip_kshint_read(*args, None, 0)
+    _check(min(n, 0))
+    xs = np.zeros((Lh.value, K.value, n, T.value), dtype=np.int64)
+    _check(min(L_.lolhip_kshint_read(*args, xs.ctypes.data_as(_i64p), xs.size), 0))
     return int(m.value), [int(q) for q in qs[:T.value]], xs
 
 

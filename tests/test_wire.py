@@ -32,11 +32,20 @@ def _messages():
     prod.field.add(name="rqlist", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.Rq")
     prodp = fd.message_type.add(name="RqProductPacked")
     prodp.field.add(name="rqlist", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqPacked")
+    poly = fd.message_type.add(name="RqPolynomial")                # lol-apps/SHE.proto
+    poly.field.add(name="coeffs", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqProduct")
+    tr = fd.message_type.add(name="TypeRep")
+    tr.field.add(name="a", number=1, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
+    tr.field.add(name="b", number=2, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
+    ks = fd.message_type.add(name="KSHint")
+    ks.field.add(name="hint", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqPolynomial")
+    ks.field.add(name="gad", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_REQUIRED, type_name=".crypto.proto.lol.TypeRep")
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = getattr(message_factory, "GetMessageClass", None)
     cls = (lambda n: get(pool.FindMessageTypeByName("crypto.proto.lol." + n))) if get else \
           (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("crypto.proto.lol." + n)))
+    _messages.KSHint = cls("KSHint")
     return cls("RqProduct"), cls("RqProductPacked")
 
 
@@ -105,3 +114,29 @@ def test_ingest_rqproduct_to_crt_basis(gpu, cpuref):
     slab = np.stack([lol_amd.rqproduct_read(b)[2] for b in blobs])
     assert np.array_equal(slab, dec)
     assert np.array_equal(P.crt(P.l(slab)), cpuref.crt(R, cpuref.l(R, dec)))
+
+
+def test_kshint_read():
+    """SHE.proto KSHint: L polynomials of K RqProduct coefficients -> [L][K][n][T] slab."""
+    import lol_amd
+    _messages()
+    m, qs = 16, [97, lm.first_good_q(16, 2 ** 40)]
+    R = Params(lm.factor_pps(m), qs)
+    rng = np.random.default_rng(3)
+    Lh, K = 3, 2
+    want = np.stack([np.stack([R.random(rng, 1)[0] for _ in range(K)]) for _ in range(Lh)])
+    msg = _messages.KSHint()
+    msg.gad.a, msg.gad.b = 123456789, 987654321
+    for j in range(Lh):
+        pl = msg.hint.add()
+        for k in range(K):
+            prod = pl.coeffs.add()
+            for t, q in enumerate(qs):
+                rq = prod.rqlist.add()
+                rq.m, rq.q = m, q
+                rq.xs.extend(_lift(v, q) for v in want[j, k, :, t])
+    m2, qs2, xs = lol_amd.kshint_read(msg.SerializeToString())
+    assert (m2, qs2) == (m, qs) and np.array_equal(xs, want)
+    broken = msg.SerializeToString()[:-30]
+    with pytest.raises(lol_amd.LolHipError):
+        lol_amd.kshint_read(broken[:40])
