@@ -15,6 +15,7 @@ rnd = random.Random(seed)
 rng = np.random.default_rng(seed)
 cpu = CpuRef()
 PRIMES = [2, 3, 5, 7, 11, 13]
+BIG = bool(os.environ.get("FUZZ_BIG"))          # only polynomials of 2048..16384 coefficients
 fails = cases = 0
 t_end = time.time() + budget
 last = time.time()
@@ -26,7 +27,7 @@ def random_m():
         for p in PRIMES:
             r = rnd.random()
             if p == 2:
-                e = rnd.choice([0, 0, 1, 2, 3, 5, 6, 7, 9, 11, 12, 13]) if r < 0.8 else 0
+                e = rnd.choice([0, 0, 1, 2, 3, 5, 6, 7, 9, 11, 12, 13, 14, 15]) if r < 0.8 else 0
             else:
                 e = rnd.choice([0, 0, 0, 1, 1, 2]) if p <= 5 else rnd.choice([0, 0, 0, 1])
             if e:
@@ -34,7 +35,7 @@ def random_m():
         if not pps:
             continue
         n = lm.totient_pps(pps)
-        if 2 <= n <= 8192:
+        if (2048 if BIG else 2) <= n <= (16384 if BIG else 8192):
             return pps
 
 
@@ -62,8 +63,9 @@ while time.time() < t_end:
         used.add(q); qs.append(q)
     B = rnd.choice([1, 2, 3, 5, 8, 9])
     R = Params(pps, qs)
-    if R.n * B * T > 60000:
-        B = max(1, 60000 // (R.n * T))
+    cap = 400000 if BIG else 60000
+    if R.n * B * T > cap:
+        B = max(1, cap // (R.n * T))
     ctx = (m, qs, B)
     try:
         P = lol_amd.Plan(pps, qs)
@@ -90,6 +92,20 @@ while time.time() < t_end:
             check("keyswitch", P.keySwitch(y, base, hint, addend=add), want, ctx + (base,))
         if T >= 2:
             check("rescale", P.rescaleDropFirst(y), sr.rescale_drop_first(R, y), ctx)
+        # a random subring E of R (drop or lower some prime powers): twace / embed / coeffs
+        sub = [(p, rnd.randint(0, e)) for p, e in pps]
+        sub = [(p, e) for p, e in sub if e > 0]
+        if sub != pps and R.n * B <= 20000 and all(lm.value_pps(pps) % q_ == 1 % q_ or True for q_ in qs):
+            RE = Params(sub, qs)
+            PE = lol_amd.Plan(sub, qs)
+            X = lol_amd.Ext(PE, P)
+            lo = RE.random(rng, B)
+            check("embedPow", X.embedPow(lo), cpu.embed_pow(RE, R, lo), ctx + (sub,))
+            check("embedDec", X.embedDec(lo), cpu.embed_dec(RE, R, lo), ctx + (sub,))
+            check("embedCRT", X.embedCRT(lo), cpu.embed_crt(RE, R, lo), ctx + (sub,))
+            check("twacePowDec", X.twacePowDec(y), cpu.twace_powdec(RE, R, y), ctx + (sub,))
+            check("twaceCRT", X.twaceCRT(y), cpu.twace_crt(RE, R, y), ctx + (sub,))
+            check("coeffs", X.coeffs(y), cpu.coeffs(RE, R, y), ctx + (sub,))
     except Exception as ex:      # noqa: BLE001
         fails += 1
         print("EXC", type(ex).__name__, ex, ctx, flush=True)
