@@ -472,6 +472,34 @@ def test_config2_full_batch(gpu, cpuref):
     # checksum of checksums against the sampled oracle rows is covered above; sortedness n/a
 
 
+def test_slabs_larger_than_4GiB(gpu, cpuref):
+    """70,000 polynomials of n = 8192: 4.6 GB per operand, past every 32-bit byte offset.  The
+    m = 2^k kernels address through per-workgroup buffer windows, the streaming kernels with
+    64-bit indices; rows from both ends and across the 4 GiB line against the oracle."""
+    torch = pytest.importorskip("torch")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24e9:
+        pytest.skip("needs 24 GB of free HBM")
+    m = 2 ** 14
+    q = lm.first_good_q(m, 2 ** 60)
+    P, R = gpu.Plan([(2, 14)], [q]), Params([(2, 14)], [q])
+    B, n = 70000, R.n
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    a = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
+    b = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
+    c = torch.empty_like(a)
+    P.polymul(a, b, out=c)
+    line = (1 << 32) // (n * 8)                                   # first polynomial past 4 GiB
+    idx = [0, 1, line - 1, line, line + 1, B - 2, B - 1]
+    want = cpuref.polymul(R, a[idx].cpu().numpy(), b[idx].cpu().numpy())
+    assert np.array_equal(c[idx].cpu().numpy(), want.reshape(len(idx), n, 1))
+    a_rows, b_rows = a[idx].cpu().numpy(), b[idx].cpu().numpy()
+    P.mul(a, b)                                                   # streaming kernel, in place, 64-bit indices
+    assert np.array_equal(a[idx].cpu().numpy(), cpuref.mul(R, a_rows, b_rows).reshape(len(idx), n, 1))
+    del a, b, c
+    torch.cuda.empty_cache()
+
+
 def test_config3_she_ciphertext_product(gpu, cpuref):
     """m = 2^15, four ~59-bit moduli: (c0,c1)*(d0,d1) -> mulG of the three products
     (SymmSHE.hs:444-452), all on the GPU, sample rows against the oracle composition."""
