@@ -13,896 +13,14 @@
 //   k_gather / k_twace_crt   twace*/embed* (Extension.hs:54-129)
 //
 // Layout at the boundary is the reference's: y[(b*n + j)*T + t] (tensor.h:69).
-#include <hip/hip_runtime.h>
-
-#include <cstdlib>
-#include <type_traits>
-#include <utility>
-
-#include "kernels.h"
-#include "zq_dev.h"
+#include "pow2_impl.h"
 
 namespace lolhip {
 
-// =============================================================================
-// power-of-two path
-// =============================================================================
-// Index convention (Tensor.hs:359-368, verified against the reference):
-//   crt:  Y[i] = sum_j a[j] * psi^(bitrev(j) * (2i+1)),  psi = omega_m, m = 2n.
-// i.e. the stored powerful basis is bit-reversed, the CRT output is in natural
-// order.  That is exactly an in-place decimation-in-time network: level s = 1..L
-// combines positions x and x + 2^(s-1) inside blocks of N = 2^s with the twiddle
-// psi_N^(2i+1), i = x mod N/2, psi_N = psi^(n/N).  The inverse runs the levels
-// backwards with Gentleman-Sande butterflies and folds mhat^-1 into level 1.
-//
-// Data movement.  A polynomial is owned by n/16 threads, 16 coefficients each in
-// registers.  Which coefficient sits where is a compile-time LAYOUT: every bit of the
-// position x is assigned either to one of the 4 register-index bits or to a thread-index
-// bit.  A butterfly level on position bit beta needs beta on a register bit, so the
-// transform is a sequence of
-//   - 4 levels on the current register bits,
-//   - an LDS transpose to the next layout (write at x in layout A, read at x in layout B),
-//   - for the 1-2 levels left over when 4 does not divide log2 n: a cross-lane
-//     v_permlane32_swap / v_permlane16_swap that exchanges a LANE bit with a register bit
-//     (no LDS, no barrier) instead of a fourth transpose.
-// Global loads/stores always use a layout whose lane bits are the low position bits
-// (consecutive lanes touch consecutive coefficients).
-
-constexpr int R = 4;
-constexpr int E = 1 << R;
-// levels whose eight twiddles are all distinct are fetched and consumed in this many parts
-// (2 or 4) in the register-lean schedule: 16 or 8 twiddle VGPRs live instead of 32
-#ifndef LOLHIP_LEVEL_PARTS
-#define LOLHIP_LEVEL_PARTS 4
-#endif
-
-// Diagnostic build (-DLOLHIP_STAMPS): per-wave s_memtime stamps at phase boundaries, written
-// to a side buffer nobody else reads.  Never enabled in the shipped library.
-#ifdef LOLHIP_STAMPS
-__device__ unsigned long long* g_stamp_buf = nullptr;
-#define LH_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-    if (g_stamp_buf && (threadIdx.x & 63) == 0) g_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (i)] = t_; } while (0)
-#else
-#define LH_STAMP(i) do {} while (0)
-#endif
-
-struct Lay {
-  int reg[R];     // position bit held by register-index bit k
-  int thr[12];    // position bit held by thread-index bit j
-  int ntb;        // number of thread bits (log2 n - 4)
-};
-constexpr bool lay_eq(const Lay& a, const Lay& b) {
-  if (a.ntb != b.ntb) return false;
-  for (int k = 0; k < R; ++k) if (a.reg[k] != b.reg[k]) return false;
-  for (int j = 0; j < a.ntb; ++j) if (a.thr[j] != b.thr[j]) return false;
-  return true;
-}
-// registers hold bits lo..lo+3, threads the remaining bits in ascending order
-constexpr Lay lay_std(int L, int lo) {
-  Lay a{};
-  a.ntb = L - R;
-  for (int k = 0; k < R; ++k) a.reg[k] = lo + k;
-  int j = 0;
-  for (int x = 0; x < L; ++x) if (x < lo || x >= lo + R) a.thr[j++] = x;
-  return a;
-}
-// registers hold bits lo..lo+3; the `nhi` bits above them sit on lane bits lb0 (, lb1);
-// the bits below fill the other thread bits in ascending order
-constexpr Lay lay_lane_hi(int L, int lo, int nhi, int lb0, int lb1) {
-  Lay a{};
-  a.ntb = L - R;
-  for (int k = 0; k < R; ++k) a.reg[k] = lo + k;
-  int x = 0;
-  for (int j = 0; j < a.ntb; ++j) {
-    if (j == lb0) a.thr[j] = lo + R;
-    else if (nhi == 2 && j == lb1) a.thr[j] = lo + R + 1;
-    else a.thr[j] = x++;
-  }
-  return a;
-}
-constexpr Lay lay_swap(Lay a, int tb, int rk) {
-  const int t = a.thr[tb];
-  a.thr[tb] = a.reg[rk];
-  a.reg[rk] = t;
-  return a;
-}
-constexpr int xreg(const Lay& a, int e) {
-  int x = 0;
-  for (int k = 0; k < R; ++k) x |= ((e >> k) & 1) << a.reg[k];
-  return x;
-}
-// position bits contributed by the thread index (runs of consecutive bits move together).
-// The run decomposition is forced through a constexpr object: left as a loop over the
-// template-parameter object, hipcc emits a RUNTIME loop of dependent global loads.
-struct LayRuns { int n; int src[12]; int len[12]; int dst[12]; };
-constexpr LayRuns lay_runs(const Lay& a) {
-  LayRuns r{};
-  for (int j = 0; j < a.ntb;) {
-    int len = 1;
-    while (j + len < a.ntb && a.thr[j + len] == a.thr[j] + len) ++len;
-    r.src[r.n] = j; r.len[r.n] = len; r.dst[r.n] = a.thr[j];
-    ++r.n;
-    j += len;
-  }
-  return r;
-}
-template <Lay A, int I>
-__device__ __forceinline__ int xthr_run(int tau) {
-  constexpr LayRuns r = lay_runs(A);
-  if constexpr (I < r.n) return (((tau >> r.src[I]) & ((1 << r.len[I]) - 1)) << r.dst[I]) | xthr_run<A, I + 1>(tau);
-  else return 0;
-}
-template <Lay A>
-__device__ __forceinline__ int xthr(int tau) { return xthr_run<A, 0>(tau); }
-
-// per-layout compile-time tables (register part of x, twiddle index and slot per butterfly)
-template <Lay A> struct LayTab {
-  int xr[E];
-  constexpr LayTab() : xr{} { for (int e = 0; e < E; ++e) xr[e] = xreg(A, e); }
-};
-template <Lay A> inline constexpr LayTab<A> lay_tab{};
-
-// one padding word per 16: lpad(a|b) = lpad(a) + lpad(b) for bit-disjoint a, b, so the
-// register part of every LDS address is an immediate offset
-constexpr int lpad(int x) { return x + (x >> 4); }
-
-// ---- arithmetic flavours, chosen per plan on the host (template parameter AR) -------------
-//  AR = 2 (every q_t < 2^30): 32-bit residues, 32-bit Shoup products (3 multiplies per butterfly),
-//         Harvey's lazy ranges [0,4q) forward / [0,2q) inverse.  This is the reference's own
-//         correct domain (its Zq overflows beyond ~2^31.5, types.h:79-84) and the HBM-bound case.
-//  AR = 1 (every q_t < 2^61): 64-bit residues, Shoup products with the 9-multiply approximate
-//         quotient (shoup_acc, result in [0,4q)); forward values in [0,8q), inverse in [0,4q).
-//  AR = 0 (2^61 <= q_t < 2^62): 10-multiply exact quotient, ranges [0,4q) / [0,2q).
-template <int AR> using VT = std::conditional_t<AR == 2, u32, u64>;
-
-// Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
-struct QK {
-  u64 q, nq, q2, nq2, q4, nq4;
-  __device__ __forceinline__ explicit QK(u64 q_) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {}
-};
-struct QK32 {
-  u32 q, q2;
-  __device__ __forceinline__ explicit QK32(u64 q_) : q((u32)q_), q2(2 * (u32)q_) {}
-};
-template <int AR> using QKT = std::conditional_t<AR == 2, QK32, QK>;
-
-__device__ __forceinline__ u32 csub32(u32 x, u32 m) { return min(x, x - m); }        // x < 2m
-// w*y mod q in [0,2q) for any 32-bit y
-__device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return w * y - __umulhi(wp, y) * q; }
-
-// forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
-template <int AR>
-__device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
-    const u32 x = csub32(X, k.q2);                    // [0,4q) -> [0,2q)
-    const u32 t = shoup32(Y, w, wp, k.q);
-    X = x + t;
-    Y = x - t + k.q2;
-  } else if constexpr (AR == 1) {
-    const u64 x = csubn(X, k.nq4);                    // [0,8q) -> [0,4q)
-    const u64 xn = shoup_acc(Y, w, wp, k.nq, x);      // x + t, t in [0,4q)
-    const u64 z = shl1_add64u(x, k.q4);                // 2x + 4q
-    X = xn;
-    Y = z - xn;                                       // x - t + 4q
-  } else {
-    const u64 x = csub(X, k.q2);
-    const u64 t = shoup_lazy(Y, w, wp, k.q);
-    X = x + t;
-    Y = x - t + k.q2;
-  }
-}
-// inverse (Gentleman-Sande) butterfly:  X' = X + Y,  Y' = (X - Y) * w
-template <int AR>
-__device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
-    const u32 s = X + Y;
-    const u32 d = X - Y + k.q2;
-    X = csub32(s, k.q2);
-    Y = shoup32(d, w, wp, k.q);
-  } else if constexpr (AR == 1) {
-    const u64 s = add64(X, Y);                        // [0,8q)
-    const u64 d = add64u(X, k.q4) - Y;                 // (0,8q)
-    X = csubn(s, k.nq4);
-    Y = shoup_acc(d, w, wp, k.nq, 0);
-  } else {
-    const u64 s = X + Y;
-    const u64 d = X - Y + k.q2;
-    X = csub(s, k.q2);
-    Y = shoup_lazy(d, w, wp, k.q);
-  }
-}
-// last inverse level: both outputs additionally scaled by mhat^-1 (crt.cpp:573-579).
-// (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
-template <int AR>
-__device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, VT<AR> s0, VT<AR> s1, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
-    const u32 s = X + Y;
-    const u32 d = X - Y + k.q2;
-    X = shoup32(s, s0, s1, k.q);
-    Y = shoup32(d, w, wp, k.q);
-  } else if constexpr (AR == 1) {
-    const u64 s = add64(X, Y);
-    const u64 d = add64u(X, k.q4) - Y;
-    X = shoup_acc(s, s0, s1, k.nq, 0);
-    Y = shoup_acc(d, w, wp, k.nq, 0);
-  } else {
-    const u64 s = X + Y;
-    const u64 d = X - Y + k.q2;
-    X = shoup_lazy(s, s0, s1, k.q);
-    Y = shoup_lazy(d, w, wp, k.q);
-  }
-}
-template <int AR> __device__ __forceinline__ VT<AR> canon_fwd(VT<AR> v, const QKT<AR>& k) {
-  if constexpr (AR == 2) return csub32(csub32(v, k.q2), k.q);
-  else {
-    if constexpr (AR == 1) v = csubn(v, k.nq4);
-    return csubn(csubn(v, k.nq2), k.nq);
-  }
-}
-template <int AR> __device__ __forceinline__ VT<AR> canon_inv(VT<AR> v, const QKT<AR>& k) {
-  if constexpr (AR == 2) return csub32(v, k.q);
-  else {
-    if constexpr (AR == 1) v = csubn(v, k.nq2);
-    return csubn(v, k.nq);
-  }
-}
-// reference-style input in (-q, q) -> [0, q)
-template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR>& k) {
-  if constexpr (AR == 2) return (u32)x + (k.q & (u32)(x >> 63));
-  else return canon_in(x, k.q);
-}
-// pointwise product of a canonical a-hat and a lazy b-hat (forward range), any range the
-// inverse transform accepts
-template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, const ModCtx& mc, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
-    const u64 x = (u64)a * b;                          // < q * 4q < 2^62
-    const u64 Q = __umul64hi(x, mc.mu);                // floor(x/q) or one less
-    return csub32((u32)(x - Q * mc.q), k.q);           // [0,2q) -> [0,q)
-  } else if constexpr (AR == 1) {
-    return mulmod(a, b, mc);                           // a < q, b < 8q: a*b < q * 2^64
-  } else {
-    return mulmod(a, canon_fwd<0>(b, k), mc);
-  }
-}
-
-// Global memory goes through buffer descriptors: address = base (SGPRs) + one 32-bit
-// per-lane offset + a wave-uniform offset, so no 64-bit address lives in VGPRs.
-typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u64& w, u64& wp) {
-  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tw, voff, const_idx * 16u, 0);
-  w = ((u64)r.y << 32) | r.x;
-  wp = ((u64)r.w << 32) | r.z;
-}
-__device__ __forceinline__ void load_tw(rsrc_t tw, u32 voff, u32 const_idx, u32& w, u32& wp) {
-  const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tw, voff, const_idx * 8u, 0);
-  w = r.x;
-  wp = r.y;
-}
-__device__ __forceinline__ u64 load_u64(rsrc_t r, u32 voff, u32 soff) {
-#ifdef LOLHIP_ABL_NO_IO       // ablation: compute-only timing, results are garbage
-  return (u64)voff * 0x9E3779B97F4A7C15ull + soff;
-#endif
-  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return ((u64)x.y << 32) | x.x;
-}
-__device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val) {
-  u32x2 x;
-  x.x = (u32)val; x.y = (u32)(val >> 32);
-#ifdef LOLHIP_ABL_NO_IO
-  if (val != 0x1234567ull) return;
-#endif
-  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
-}
-
-// Where a level's twiddles come from:
-//  * index bits all on registers (the thread part of x mod 2^beta is empty): wave-uniform,
-//    read with SCALAR loads — no texture-path traffic at all;
-//  * beta <= 8: from a per-workgroup LDS copy of table entries [16, 512) (levels 5..9) —
-//    the texture path costs 16 clk per 1 KiB wave-load even when 64 lanes hit 16 addresses,
-//    and at 60 such loads per wave it, not the ALU, was bounding the transform;
-//  * otherwise (the top levels, whose tables are 8 KiB..64 KiB): buffer loads, L2-served.
-constexpr int TWL_LO = 16, TWL_HI = 512;              // LDS-resident table entries [lo, hi)
-constexpr int TWL_MIN_L = 11;                         // smaller polynomials: the copy costs more than it saves
-constexpr int twl_words(int n) { return n >= (1 << TWL_MIN_L) ? 2 * (TWL_HI - TWL_LO) : 0; }
-
-template <typename V> struct TwCtxT {
-  rsrc_t fwd, inv;
-  const V *pf, *pi;     // this component's tables as plain pointers (scalar loads)
-  const V* lds_tw;      // LDS copy of entries [16,512) of the table currently in use
-  u32 comp;             // byte offset of this RNS component's table
-  V sc0, sc1;           // Shoup pair of mhat^-1
-};
-template <Lay A, int K> constexpr bool tw_uniform() {
-  for (int j = 0; j < A.ntb; ++j) if (A.thr[j] < A.reg[K]) return false;
-  return true;
-}
-
-// ---- twiddles: fetched a whole register pass ahead ------------------------------------
-// Level on register bit K of layout A: butterflies pair e and e|1<<K; the twiddle index is
-// x mod 2^beta (beta = A.reg[K]), whose register part is a compile-time constant.  Threads
-// issue the (deduplicated) loads for ALL levels of a pass before the LDS transpose that
-// precedes it, so L2 latency overlaps the exchange and the barrier.
-constexpr int tw_cidx(const Lay& a, int k, int e) {
-  const int beta = a.reg[k];
-  return (1 << beta) + (xreg(a, e) & ((1 << beta) - 1));
-}
-// ordinal (0..7) of the first butterfly of level k that uses the same twiddle as butterfly e
-// number of distinct twiddles of level k in layout a
-constexpr int tw_distinct(const Lay& a, int k) {
-  int cnt = 0;
-  for (int e = 0; e < E; ++e) {
-    if (e & (1 << k)) continue;
-    bool first = true;
-    for (int f = 0; f < e; ++f) if (!(f & (1 << k)) && tw_cidx(a, k, f) == tw_cidx(a, k, e)) first = false;
-    cnt += first ? 1 : 0;
-  }
-  return cnt;
-}
-constexpr int tw_slot(const Lay& a, int k, int e) {
-  int ord = 0;
-  for (int f = 0; f < E; ++f) {
-    if (f & (1 << k)) continue;
-    if (tw_cidx(a, k, f) == tw_cidx(a, k, e)) return ord;
-    ++ord;
-  }
-  return 0;
-}
-template <Lay A, int K> struct LevelTab {
-  int cidx[E], slot[E];
-  constexpr LevelTab() : cidx{}, slot{} { for (int e = 0; e < E; ++e) { cidx[e] = tw_cidx(A, K, e); slot[e] = tw_slot(A, K, e); } }
-};
-template <Lay A, int K> inline constexpr LevelTab<A, K> level_tab{};
-template <typename V> struct LevelTwT { V w[8], wp[8]; };
-
-template <bool INV, Lay A, int K, int HALF = -1, typename V>
-__device__ __forceinline__ void tw_fetch(LevelTwT<V>& t, const TwCtxT<V>& tw, int xt) {
-  constexpr int beta = A.reg[K];
-#ifdef LOLHIP_ABL_NO_TW       // ablation: no twiddle traffic
-#pragma unroll
-  for (int s = 0; s < 8; ++s) { t.w[s] = tw.sc0 + s; t.wp[s] = tw.sc1 + K; }
-  return;
-#endif
-  const u32 voff = tw.comp + (u32)(xt & ((1 << beta) - 1)) * (u32)(2 * sizeof(V));
-  const V* sp = INV ? tw.pi : tw.pf;
-  int ord = 0;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (e & (1 << K)) continue;
-    if (level_tab<A, K>.slot[e] == ord && (HALF < 0 || ord / (8 / LOLHIP_LEVEL_PARTS) == HALF)) {
-      const int cidx = level_tab<A, K>.cidx[e];
-      if constexpr (tw_uniform<A, K>()) {
-        t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
-      } else if constexpr (A.ntb + R >= TWL_MIN_L && (2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
-        const V* lp = tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1)));
-        if constexpr (sizeof(V) == 8) { const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
-        else { const uint2 r = *reinterpret_cast<const uint2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
-      } else {
-        load_tw(INV ? tw.inv : tw.fwd, voff, (u32)cidx, t.w[ord], t.wp[ord]);
-      }
-    }
-    ++ord;
-  }
-}
-// copy entries [16, 512) of one component's table into LDS (NT threads of one polynomial)
-template <int NT, typename V>
-__device__ __forceinline__ void tw_fill_lds(V* dst, rsrc_t src, u32 comp, int n, int tau) {
-  const int cnt = (n < TWL_HI ? n : TWL_HI) - TWL_LO;
-  for (int i = tau; i < cnt; i += NT) {
-    if constexpr (sizeof(V) == 8) {
-      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(src, comp + (u32)(TWL_LO + i) * 16u, 0, 0);
-      *reinterpret_cast<u32x4*>(dst + 2 * i) = r;
-    } else {
-      const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(src, comp + (u32)(TWL_LO + i) * 8u, 0, 0);
-      *reinterpret_cast<u32x2*>(dst + 2 * i) = r;
-    }
-  }
-}
-template <int AR, bool INV, Lay A, int K, int HALF = -1>
-__device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t, const TwCtxT<VT<AR>>& tw, const QKT<AR>& qk) {
-  constexpr int beta = A.reg[K];
-#ifdef LOLHIP_ABL_NO_BFLY     // ablation: keep the twiddles live, skip the arithmetic
-#pragma unroll
-  for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(t.w[s]), "v"(t.wp[s]));
-  return;
-#endif
-  int ordb = -1;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (e & (1 << K)) continue;
-    ++ordb;
-    if (HALF >= 0 && ordb / (8 / LOLHIP_LEVEL_PARTS) != HALF) continue;
-    const int s = level_tab<A, K>.slot[e];
-    if constexpr (!INV) bfly_fwd<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
-    else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
-    else bfly_inv<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
-  }
-}
-
-// exchange lane bit TB (4 or 5) with register bit RK: 16 v_permlane*_swap, no LDS
-template <int TB, int RK>
-__device__ __forceinline__ void lane_swap(u32 (&v)[E]) {
-  static_assert(TB == 4 || TB == 5, "only lane bits 4 and 5 have swap instructions");
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (e & (1 << RK)) continue;
-    const int f = e | (1 << RK);
-    u32x2 r;
-    if constexpr (TB == 5) r = __builtin_amdgcn_permlane32_swap(v[e], v[f], false, false);
-    else r = __builtin_amdgcn_permlane16_swap(v[e], v[f], false, false);
-    v[e] = r.x;
-    v[f] = r.y;
-  }
-}
-template <int TB, int RK>
-__device__ __forceinline__ void lane_swap(u64 (&v)[E]) {
-  static_assert(TB == 4 || TB == 5, "only lane bits 4 and 5 have swap instructions");
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (e & (1 << RK)) continue;
-    const int f = e | (1 << RK);
-    u32x2 lo, hi;
-    if constexpr (TB == 5) {
-      lo = __builtin_amdgcn_permlane32_swap((u32)v[e], (u32)v[f], false, false);
-      hi = __builtin_amdgcn_permlane32_swap((u32)(v[e] >> 32), (u32)(v[f] >> 32), false, false);
-    } else {
-      lo = __builtin_amdgcn_permlane16_swap((u32)v[e], (u32)v[f], false, false);
-      hi = __builtin_amdgcn_permlane16_swap((u32)(v[e] >> 32), (u32)(v[f] >> 32), false, false);
-    }
-    v[e] = ((u64)hi.x << 32) | lo.x;
-    v[f] = ((u64)hi.y << 32) | lo.y;
-  }
-}
-
-// LDS transpose A -> B, split so that independent work (twiddle fetches) sits between the
-// halves.  WAVE-LOCAL transposes (both layouts keep a wave inside its own 1024-coefficient
-// block) need no s_barrier at all: a wave's LDS instructions execute in order.  Only the one
-// transpose per transform that crosses waves pays two workgroup barriers; the one protecting
-// the previous reads comes FIRST, when every wave has long finished them.
-template <Lay A, Lay B, bool CROSS_WAVE, typename V>
-__device__ __forceinline__ void transpose_put(V (&v)[E], V* lds, int tau) {
-#ifdef LOLHIP_ABL_NO_XPOSE
-  return;
-#endif
-  if constexpr (!lay_eq(A, B)) {
-    if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    V* wp = lds + lpad(xthr<A>(tau));
-#pragma unroll
-    for (int e = 0; e < E; ++e) wp[lpad(lay_tab<A>.xr[e])] = v[e];
-  }
-}
-template <Lay A, Lay B, bool CROSS_WAVE, typename V>
-__device__ __forceinline__ void transpose_get(V (&v)[E], V* lds, int tau) {
-#ifdef LOLHIP_ABL_NO_XPOSE
-  return;
-#endif
-  if constexpr (!lay_eq(A, B)) {
-    if constexpr (CROSS_WAVE) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-    const V* rp = lds + lpad(xthr<B>(tau));
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = rp[lpad(lay_tab<B>.xr[e])];
-  }
-}
-
-// layout with explicit register bits; thread bits listed lowest first
-constexpr Lay lay_make(int L, int r0, int r1, int r2, int r3, const int* thr_bits) {
-  Lay a{};
-  a.ntb = L - R;
-  a.reg[0] = r0; a.reg[1] = r1; a.reg[2] = r2; a.reg[3] = r3;
-  for (int j = 0; j < a.ntb; ++j) a.thr[j] = thr_bits[j];
-  return a;
-}
-
-// Compile-time schedule for n = 2^L.  LW = min(L,10) levels run WAVE-LOCALLY (a wave owns a
-// block of 1024 consecutive coefficients, or 2^(10-L) whole polynomials when L < 10):
-//   W0: registers = bits 0..3                      -> levels 1..4
-//   W1: registers = bits 4..7, lane bits 4,5 = 8,9  -> levels 5..8, lane swaps -> levels 9, 10
-//       (for L < 8 an overlapping window of the top four bits instead)
-// and the remaining L-10 levels after ONE cross-wave transpose into
-//   G:  registers = bits L-4..L-1                   -> levels 11..L
-// G is also the coalesced global-memory layout (consecutive lanes = consecutive coefficients).
-template <int L> struct Sched {
-  static constexpr int NTB = L - R;
-  static constexpr int LW = L < 10 ? L : 10;
-  static constexpr bool HAS_G = L > 10;
-  static constexpr Lay w0() { return lay_std(L, 0); }
-  static constexpr bool W1_WINDOW = (LW > 4 && LW < 8);          // overlapping window, no swaps
-  static constexpr bool HAS_W1 = LW > 4;
-  static constexpr Lay w1() {
-    if (W1_WINDOW) return lay_std(L, L - R);
-    int thr[12] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15};    // t0-3 = bits 0-3, t4 = 8, t5 = 9, waves = 10+
-    return lay_make(L, 4, 5, 6, 7, thr);
-  }
-  static constexpr int W1_K0 = W1_WINDOW ? (R - (LW - 4)) : 0;   // first register bit with work in W1
-  static constexpr int NSWAP = LW >= 8 ? LW - 8 : 0;             // levels reached through lane swaps (0..2)
-  static constexpr Lay w1a() { return lay_swap(w1(), 4, 3); }    // lane bit 4 <-> register bit 3: bit 8
-  static constexpr Lay w1b() { return lay_swap(w1a(), 5, 2); }   // lane bit 5 <-> register bit 2: bit 9
-  static constexpr Lay wave_end() { return NSWAP == 2 ? w1b() : NSWAP == 1 ? w1a() : HAS_W1 ? w1() : w0(); }
-  static constexpr Lay g() { return lay_std(L, L - R); }
-  static constexpr int G_K0 = R - (L - 10);                      // first register bit with work in G
-  // coalesced load/store layout for powerful-basis data that keeps a wave inside its block
-  static constexpr Lay io() {
-    if (L < 10) return lay_std(L, L - R);
-    int thr[12] = {0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15};
-    return lay_make(L, 6, 7, 8, 9, thr);
-  }
-  static constexpr Lay final_layout() { return HAS_G ? g() : wave_end(); }
-};
-
-template <int AR, bool INV, Lay A, int K0>
-__device__ __forceinline__ void fetch4(LevelTwT<VT<AR>> (&t)[R], const TwCtxT<VT<AR>>& tw, int xt) {
-  if constexpr (K0 <= 0) tw_fetch<INV, A, 0>(t[0], tw, xt);
-  if constexpr (K0 <= 1) tw_fetch<INV, A, 1>(t[1], tw, xt);
-  if constexpr (K0 <= 2) tw_fetch<INV, A, 2>(t[2], tw, xt);
-  if constexpr (K0 <= 3) tw_fetch<INV, A, 3>(t[3], tw, xt);
-}
-// register-lean variant: fetch each level's twiddles right before the level (<= 32 VGPRs live)
-template <int AR, bool INV, Lay A, int K>
-__device__ __forceinline__ void level_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
-  using LevelTw = LevelTwT<VT<AR>>;
-  if constexpr (tw_distinct(A, K) == 8 && sizeof(VT<AR>) == 8) {
-    // all eight twiddles distinct (32 VGPRs): LOLHIP_LEVEL_PARTS parts keep the live set small
-    [&]<int... PART>(std::integer_sequence<int, PART...>) {
-      (([&] { LevelTw t; tw_fetch<INV, A, K, PART>(t, tw, xt); level<AR, INV, A, K, PART>(v, t, tw, qk); }()), ...);
-    }(std::make_integer_sequence<int, LOLHIP_LEVEL_PARTS>{});
-  } else {
-    LevelTw t; tw_fetch<INV, A, K>(t, tw, xt); level<AR, INV, A, K>(v, t, tw, qk);
-  }
-}
-template <int AR, Lay A, int K0>
-__device__ __forceinline__ void levels4_jit(VT<AR> (&v)[E], const TwCtxT<VT<AR>>& tw, int xt, const QKT<AR>& qk) {
-  if constexpr (K0 <= 0) level_jit<AR, false, A, 0>(v, tw, xt, qk);
-  if constexpr (K0 <= 1) level_jit<AR, false, A, 1>(v, tw, xt, qk);
-  if constexpr (K0 <= 2) level_jit<AR, false, A, 2>(v, tw, xt, qk);
-  if constexpr (K0 <= 3) level_jit<AR, false, A, 3>(v, tw, xt, qk);
-}
-template <int AR, bool INV, Lay A, int K0>
-__device__ __forceinline__ void levels4(VT<AR> (&v)[E], const LevelTwT<VT<AR>> (&t)[R], const TwCtxT<VT<AR>>& tw, const QKT<AR>& qk) {
-  if constexpr (!INV) {
-    if constexpr (K0 <= 0) level<AR, false, A, 0>(v, t[0], tw, qk);
-    if constexpr (K0 <= 1) level<AR, false, A, 1>(v, t[1], tw, qk);
-    if constexpr (K0 <= 2) level<AR, false, A, 2>(v, t[2], tw, qk);
-    if constexpr (K0 <= 3) level<AR, false, A, 3>(v, t[3], tw, qk);
-  } else {
-    if constexpr (K0 <= 3) level<AR, true, A, 3>(v, t[3], tw, qk);
-    if constexpr (K0 <= 2) level<AR, true, A, 2>(v, t[2], tw, qk);
-    if constexpr (K0 <= 1) level<AR, true, A, 1>(v, t[1], tw, qk);
-    if constexpr (K0 <= 0) level<AR, true, A, 0>(v, t[0], tw, qk);
-  }
-}
-
-// forward transform; data arrives in registers in layout PREV, leaves in Sched<L>::final_layout().
-// LEAN: the caller keeps 32 more VGPRs live (a-hat during b's transform in the fused poly-mul),
-// so twiddles are fetched level by level instead of a pass ahead.
-// An opaque copy of a value: addresses derived from the copy cannot be CSE'd with (and kept
-// live since) an earlier pass's; recomputing a few address adds per pass is far cheaper than
-// a dozen VGPRs held across all three transforms of the fused poly-mul.
-__device__ __forceinline__ int fresh(int x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false>
-__device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
-  using LevelTw = LevelTwT<VT<AR>>;
-  using S = Sched<L>;
-  {   // W0: levels 1..4
-    constexpr Lay A = S::w0();
-    const int tau = fresh(tau_in);
-    // the previous transform's cross-wave reads may still be in flight in other waves
-    if constexpr (S::HAS_G && !lay_eq(PREV, A)) __syncthreads();
-    transpose_put<PREV, A, false>(v, lds, tau);
-    if constexpr (LEAN) {
-      transpose_get<PREV, A, false>(v, lds, tau);
-      levels4_jit<AR, A, 0>(v, tw, xthr<A>(tau), qk);
-    } else {
-      LevelTw t[R];
-      fetch4<AR, false, A, 0>(t, tw, xthr<A>(tau));
-      transpose_get<PREV, A, false>(v, lds, tau);
-      LH_STAMP(SB + 2);
-      levels4<AR, false, A, 0>(v, t, tw, qk);
-      LH_STAMP(SB + 3);
-    }
-  }
-  if constexpr (S::HAS_W1) {   // W1: levels 5..8 (or the window), then lane swaps for 9, 10
-    constexpr Lay A = S::w1();
-    const int tau = fresh(tau_in);
-    if constexpr (LEAN) {
-      transpose_put<S::w0(), A, false>(v, lds, tau);
-      transpose_get<S::w0(), A, false>(v, lds, tau);
-      levels4_jit<AR, A, S::W1_K0>(v, tw, xthr<A>(tau), qk);
-      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level_jit<AR, false, S::w1a(), 3>(v, tw, xthr<S::w1a()>(tau), qk); }
-      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level_jit<AR, false, S::w1b(), 2>(v, tw, xthr<S::w1b()>(tau), qk); }
-    } else {
-      LevelTw t[R];
-      transpose_put<S::w0(), A, false>(v, lds, tau);
-      fetch4<AR, false, A, S::W1_K0>(t, tw, xthr<A>(tau));
-      transpose_get<S::w0(), A, false>(v, lds, tau);
-      LH_STAMP(SB + 4);
-      // levels 5..8, with the twiddles of the two lane-swap levels fetched as registers free up
-      if constexpr (S::W1_K0 <= 0) level<AR, false, A, 0>(v, t[0], tw, qk);
-      if constexpr (S::W1_K0 <= 1) level<AR, false, A, 1>(v, t[1], tw, qk);
-      if constexpr (S::W1_K0 <= 2) level<AR, false, A, 2>(v, t[2], tw, qk);
-      LevelTw ua, ub;
-      if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
-      level<AR, false, A, 3>(v, t[3], tw, qk);
-      LH_STAMP(SB + 5);
-      if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
-      if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<AR, false, S::w1a(), 3>(v, ua, tw, qk); }
-      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<AR, false, S::w1b(), 2>(v, ub, tw, qk); }
-      LH_STAMP(SB + 6);
-    }
-  }
-  if constexpr (S::HAS_G) {    // the one cross-wave exchange, then levels 11..L
-    constexpr Lay A = S::g();
-    const int tau = fresh(tau_in);
-    transpose_put<S::wave_end(), A, false>(v, lds, tau);   // writes stay inside the wave's own block
-    if constexpr (LEAN) {
-      transpose_get<S::wave_end(), A, true>(v, lds, tau);  // barrier, then read across blocks
-      levels4_jit<AR, A, S::G_K0>(v, tw, xthr<A>(tau), qk);
-    } else {
-      LevelTw t[R];
-      fetch4<AR, false, A, S::G_K0>(t, tw, xthr<A>(tau));
-      transpose_get<S::wave_end(), A, true>(v, lds, tau);
-      LH_STAMP(SB + 7);
-      levels4<AR, false, A, S::G_K0>(v, t, tw, qk);
-      LH_STAMP(SB + 8);
-    }
-  }
-}
-
-// inverse transform; data arrives in Sched<L>::final_layout(), leaves in layout NEXT
-template <int AR, int L, Lay NEXT>
-__device__ __forceinline__ void inv_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
-  using LevelTw = LevelTwT<VT<AR>>;
-  using S = Sched<L>;
-  if constexpr (S::HAS_G) {
-    constexpr Lay A = S::g();
-    const int tau = fresh(tau_in);
-    LevelTw t[R];
-    fetch4<AR, true, A, S::G_K0>(t, tw, xthr<A>(tau));
-    levels4<AR, true, A, S::G_K0>(v, t, tw, qk);
-    transpose_put<A, S::wave_end(), true>(v, lds, tau);    // barrier (earlier readers), write across blocks
-  }
-  if constexpr (S::HAS_W1) {
-    constexpr Lay A = S::w1();
-    const int tau = fresh(tau_in);
-    const int xt = xthr<A>(tau);
-    LevelTw ua, ub, t[R];
-    if constexpr (S::NSWAP >= 2) tw_fetch<true, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
-    if constexpr (S::NSWAP >= 1) tw_fetch<true, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
-    if constexpr (S::NSWAP == 0) fetch4<AR, true, A, S::W1_K0>(t, tw, xt);
-    if constexpr (S::HAS_G) transpose_get<S::g(), S::wave_end(), true>(v, lds, tau);   // barrier, read own block
-    if constexpr (S::NSWAP >= 2) { level<AR, true, S::w1b(), 2>(v, ub, tw, qk); lane_swap<5, 2>(v); }
-    if constexpr (S::NSWAP >= 1) {
-      tw_fetch<true, A, 3>(t[3], tw, xt);
-      level<AR, true, S::w1a(), 3>(v, ua, tw, qk);
-      lane_swap<4, 3>(v);
-      tw_fetch<true, A, 2>(t[2], tw, xt);
-      tw_fetch<true, A, 1>(t[1], tw, xt);
-      tw_fetch<true, A, 0>(t[0], tw, xt);
-    }
-    levels4<AR, true, A, S::W1_K0>(v, t, tw, qk);
-    transpose_put<A, S::w0(), false>(v, lds, tau);
-  }
-  {
-    constexpr Lay A = S::w0();
-    const int tau = fresh(tau_in);
-    LevelTw t[R];
-    fetch4<AR, true, A, 0>(t, tw, xthr<A>(tau));
-    if constexpr (S::HAS_W1) transpose_get<S::w1(), A, false>(v, lds, tau);
-    levels4<AR, true, A, 0>(v, t, tw, qk);
-    transpose_put<A, NEXT, false>(v, lds, tau);
-    transpose_get<A, NEXT, false>(v, lds, tau);
-  }
-}
-
-constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
-
-// MODE 0: crt in place, 1: crtInv in place, 2: c = crtInv(crt(a) * crt(b))
-// TU ("T uniform"): the launch has a single modulus, so t = 0 for every lane even when a wave
-// holds several short polynomials — the per-modulus constants stay in SGPRs (instantiated for
-// n <= 512 only; longer polynomials own whole waves and are uniform anyway)
-template <int L, int MODE, int AR, bool TU = false>
-__global__ void __launch_bounds__(pow2_threads(L), AR == 2 ? 8 : 4)
-k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
-       const VT<AR>* __restrict__ tw_fwd, const VT<AR>* __restrict__ tw_inv, const VT<AR>* __restrict__ scale,
-       const ModCtx* __restrict__ mod, int xcd_map) {
-  using S = Sched<L>;
-  using V = VT<AR>;
-  constexpr int n = 1 << L;
-  constexpr int NT = 1 << (L - R);                  // threads per polynomial
-  constexpr int PPW = NT >= 256 ? 1 : 256 / NT;     // polynomials per workgroup
-  constexpr int LDSW = n + n / 16 + twl_words(n);   // padded coefficients + twiddle copy, per polynomial (V words)
-  constexpr u32 TWB = 2 * sizeof(V);                // bytes per twiddle entry
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V* lds = reinterpret_cast<V*>(smem) + (threadIdx.x / NT) * LDSW;
-  V* lds_tw = lds + n + n / 16;
-  const int tau = threadIdx.x % NT;
-
-  // work item -> (b, t); with xcd_map the T components of one polynomial land on
-  // workgroups that share an XCD (equal blockIdx % 8) so its cache lines are
-  // fetched from HBM once.  Placement only affects speed.
-  const i64 item0 = (i64)blockIdx.x * PPW;             // wave-uniform
-  const int slot = (PPW == 1) ? 0 : (int)(threadIdx.x / NT);
-  const i64 item = item0 + slot;
-  i64 b, b0; int t;
-  if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
-  else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
-  if constexpr (TU) { b = item; t = 0; b0 = item0; }
-
-  if constexpr (NT >= 64) {           // a wave never straddles two polynomials: make that provable to hipcc
-    t = __builtin_amdgcn_readfirstlane(t);
-    b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
-  }
-  b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
-  const QKT<AR> qk(mod[t].q);
-  // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
-  // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
-  // stores are dropped by the hardware range check.
-  const u64 win = (u64)(B - b0) * n * T * 8;
-  const u32 wbytes = win > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)win;
-  const size_t wbase = (size_t)b0 * n * T;
-  const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + wbase), 0, wbytes, 0x00020000);
-  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
-  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + (MODE == 2 ? wbase : 0)), 0, MODE == 2 ? wbytes : 0, 0x00020000);
-  TwCtxT<V> tw;
-  tw.fwd = __builtin_amdgcn_make_buffer_rsrc((void*)tw_fwd, 0, (u32)T * n * TWB, 0x00020000);
-  tw.inv = __builtin_amdgcn_make_buffer_rsrc((void*)tw_inv, 0, (u32)T * n * TWB, 0x00020000);
-  tw.comp = (u32)t * (u32)n * TWB;
-  tw.pf = tw_fwd + (size_t)t * n * 2;
-  tw.pi = tw_inv + (size_t)t * n * 2;
-  tw.lds_tw = lds_tw;
-  // levels 5..9 read their twiddles from LDS; (re)filled before the transform direction changes.
-  // Visibility: for L > 10 a workgroup barrier follows before first use; for L <= 10 the
-  // polynomial's own wave does both the fill and the reads.
-  if constexpr (L >= TWL_MIN_L) tw_fill_lds<NT>(lds_tw, (MODE == 1) ? tw.inv : tw.fwd, tw.comp, n, tau);
-  tw.sc0 = scale[(size_t)t * 2];
-  tw.sc1 = scale[(size_t)t * 2 + 1];
-
-  constexpr Lay LIO = S::io();              // global I/O of powerful-basis data
-  constexpr Lay LFIN = S::final_layout();   // where the forward transform leaves the CRT coefficients
-  const u32 uT8 = (u32)T * 8u;
-  const u32 pofs = ((u32)(b - b0) * (u32)n * (u32)T + (u32)t) * 8u;       // this polynomial inside the window
-  const u32 off_io = pofs + (u32)xthr<LIO>(tau) * uT8;
-  const u32 off_fin = pofs + (u32)xthr<LFIN>(tau) * uT8;
-
-  V v[E];
-  LH_STAMP(0);
-#ifdef LOLHIP_STAMPS
-  if (g_stamp_buf && (threadIdx.x & 63) == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_stamp_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + 30] = ((unsigned long long)xcc << 32) | hwid;
-  }
-#endif
-  if constexpr (MODE == 0 || MODE == 2) {
-    const rsrc_t src = (MODE == 2) ? ra : ry;
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk);
-    LH_STAMP(1);
-    fwd_transform<AR, L, LIO>(v, lds, tw, tau, qk);
-    if constexpr (MODE == 0) LH_STAMP(20);
-  }
-  if constexpr (MODE == 2) {
-    // a-hat stays in registers (canonical) while b is transformed with the register-lean
-    // twiddle schedule; nothing is parked in HBM, and c may alias a and/or b freely because
-    // both operands are fully read before the first store to c.
-    V va[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) va[e] = canon_fwd<AR>(v[e], qk);
-    LH_STAMP(9);
-    const bool square = (a_in == b_in);
-    if (!square) {
-      u64 raw[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) raw[e] = load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8);
-      // keep the 16 loads back to back: at this register pressure the scheduler otherwise
-      // sinks each load to its use and the wave pays 16 serial HBM round trips
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)raw[e], qk);
-      LH_STAMP(11);
-      fwd_transform<AR, L, LIO, 10, true>(v, lds, tw, tau, qk);
-    }
-    LH_STAMP(19);
-    const ModCtx mc = mod[t];     // re-read here: keeping it live across the transforms costs registers
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = pmul<AR>(va[e], square ? va[e] : v[e], mc, qk);
-    LH_STAMP(22);
-  }
-  if constexpr (MODE == 2 && L >= TWL_MIN_L) {
-    // every wave is past its last forward use of the LDS twiddles (the cross-wave barrier of
-    // the final forward stage, or program order inside a wave): switch the copy to the inverse table
-    if constexpr (L > 10) __syncthreads();
-    tw_fill_lds<NT>(lds_tw, tw.inv, tw.comp, n, tau);
-  }
-  if constexpr (MODE == 1) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk);
-  }
-  if constexpr (MODE == 0) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, (u64)canon_fwd<AR>(v[e], qk));
-    LH_STAMP(21);
-  } else {
-    LH_STAMP(23);
-    inv_transform<AR, L, LIO>(v, lds, tw, tau, qk);
-    LH_STAMP(24);
-#pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)lay_tab<LIO>.xr[e] * uT8, (u64)canon_inv<AR>(v[e], qk));
-    LH_STAMP(25);
-  }
-}
-
-template <int L, int MODE, int AR>
-static hipError_t launch_pow2_L(const Pow2Launch& a) {
-  constexpr int n = 1 << L;
-  constexpr int NT = 1 << (L - R);
-  constexpr int PPW = NT >= 256 ? 1 : 256 / NT;
-  constexpr int LDSW = n + n / 16 + twl_words(n);
-  const size_t lds_bytes = (size_t)PPW * LDSW * sizeof(VT<AR>);
-  const i64 items = a.B * a.T;
-  const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
-  const i64 grid = (items + PPW - 1) / PPW;
-  if (grid == 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if constexpr (NT < 64 && AR != 2) {
-    if (a.T == 1) {
-      hipLaunchKernelGGL((k_pow2<L, MODE, AR, true>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
-                         a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
-                         static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
-      return hipGetLastError();
-    }
-  }
-  hipLaunchKernelGGL((k_pow2<L, MODE, AR>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
-                     a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
-                     static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
-  return hipGetLastError();
-}
-
-template <int MODE, int AR>
-static hipError_t launch_pow2_mode(const Pow2Launch& a) {
-  switch (a.L) {
-    case 4: return launch_pow2_L<4, MODE, AR>(a);
-    case 5: return launch_pow2_L<5, MODE, AR>(a);
-    case 6: return launch_pow2_L<6, MODE, AR>(a);
-    case 7: return launch_pow2_L<7, MODE, AR>(a);
-    case 8: return launch_pow2_L<8, MODE, AR>(a);
-    case 9: return launch_pow2_L<9, MODE, AR>(a);
-    case 10: return launch_pow2_L<10, MODE, AR>(a);
-    case 11: return launch_pow2_L<11, MODE, AR>(a);
-    case 12: return launch_pow2_L<12, MODE, AR>(a);
-    case 13: return launch_pow2_L<13, MODE, AR>(a);
-    case 14: return launch_pow2_L<14, MODE, AR>(a);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-#ifdef LOLHIP_STAMPS
-extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dev, sizeof(dev));
-}
-#endif
-
-template <int AR>
-static hipError_t launch_pow2_ar(const Pow2Launch& a, int mode) {
-  switch (mode) {
-    case 0: return launch_pow2_mode<0, AR>(a);
-    case 1: return launch_pow2_mode<1, AR>(a);
-    case 2: return launch_pow2_mode<2, AR>(a);
-    default: return hipErrorInvalidValue;
-  }
-}
+// the arithmetic classes of the m = 2^k path live in pow2_ar{0,1,2,3}.hip
+extern template hipError_t launch_pow2_ar<0>(const Pow2Launch&, int);
+extern template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
+extern template hipError_t launch_pow2_ar<2>(const Pow2Launch&, int);
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (a.arith) {
     case 0: return launch_pow2_ar<0>(a, mode);

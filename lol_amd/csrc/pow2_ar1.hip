@@ -1,0 +1,10 @@
+// lol_amd/csrc/pow2_ar1.hip — the m = 2^k kernels of arithmetic class AR = 1 (see pow2_impl.h)
+#include "pow2_impl.h"
+namespace lolhip {
+template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
+}  // namespace lolhip
+#ifdef LOLHIP_STAMPS
+extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lolhip::g_stamp_buf), &dev, sizeof(dev));
+}
+#endif
