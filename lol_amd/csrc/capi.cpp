@@ -89,8 +89,8 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
   Pow2Launch l;
   l.stream = s; l.y = y; l.a = a; l.b = b; l.B = B; l.T = P.T; l.L = P.pow2.L;
   l.mod = P.d_mod;
-  if (P.pow2.d_tw_fwd32) {          // every modulus < 2^30: 32-bit arithmetic
-    l.arith = 2; l.tw_fwd = P.pow2.d_tw_fwd32; l.tw_inv = P.pow2.d_tw_inv32; l.scale = P.pow2.d_scale32;
+  if (P.pow2.arith32) {             // every modulus < 2^30 (class 2) or < 2^31 (class 3): 32-bit arithmetic
+    l.arith = P.pow2.arith32; l.tw_fwd = P.pow2.d_tw_fwd32; l.tw_inv = P.pow2.d_tw_inv32; l.scale = P.pow2.d_scale32;
   } else {
     l.arith = 1;
     for (u64 q : P.qs) if (q >= (1ull << 61)) l.arith = 0;
@@ -362,7 +362,7 @@ int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2
   if (B == 0) return LOLHIP_OK;
   const Plan& P = p->P;
   // one fused pass when the plan is in the 32-bit class of the m = 2^k path (every q_t < 2^30)
-  if (P.is_pow2 && P.pow2.d_tw_fwd32 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
+  if (P.is_pow2 && P.pow2.arith32 == 2 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !getenv("LOLHIP_KEYSWITCH_UNFUSED")) {
     KeySwitchLaunch l;
     l.stream = (hipStream_t)stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;

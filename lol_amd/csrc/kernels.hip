@@ -21,11 +21,13 @@ namespace lolhip {
 extern template hipError_t launch_pow2_ar<0>(const Pow2Launch&, int);
 extern template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
 extern template hipError_t launch_pow2_ar<2>(const Pow2Launch&, int);
+extern template hipError_t launch_pow2_ar<3>(const Pow2Launch&, int);
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (a.arith) {
     case 0: return launch_pow2_ar<0>(a, mode);
     case 1: return launch_pow2_ar<1>(a, mode);
     case 2: return launch_pow2_ar<2>(a, mode);
+    case 3: return launch_pow2_ar<3>(a, mode);
     default: return hipErrorInvalidValue;
   }
 }

@@ -363,9 +363,10 @@ int plan_upload(Plan& P) {
     if ((rc = upload(&P.pow2.d_tw_fwd, fwd))) return rc;
     if ((rc = upload(&P.pow2.d_tw_inv, inv))) return rc;
     if ((rc = upload(&P.pow2.d_scale, sc))) return rc;
-    bool small = true;
-    for (u64 q : P.qs) if (q >= (1ull << 30)) small = false;
-    if (small) {   // 32-bit Shoup pairs: wp = floor(w * 2^32 / q)
+    P.pow2.arith32 = 2;
+    for (u64 q : P.qs) { if (q >= (1ull << 30)) P.pow2.arith32 = 3; }
+    for (u64 q : P.qs) { if (q >= (1ull << 31)) P.pow2.arith32 = 0; }
+    if (P.pow2.arith32) {   // 32-bit Shoup pairs: wp = floor(w * 2^32 / q)
       std::vector<uint32_t> f32(fwd.size()), i32(inv.size()), s32(sc.size());
       for (int t = 0; t < T; ++t) {
         const u64 q = P.qs[(size_t)t];

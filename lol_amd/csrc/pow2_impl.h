@@ -140,10 +140,14 @@ constexpr int lpad(int x) { return x + (x >> 4); }
 //  AR = 2 (every q_t < 2^30): 32-bit residues, 32-bit Shoup products (3 multiplies per butterfly),
 //         Harvey's lazy ranges [0,4q) forward / [0,2q) inverse.  This is the reference's own
 //         correct domain (its Zq overflows beyond ~2^31.5, types.h:79-84) and the HBM-bound case.
+//  AR = 3 (every q_t < 2^31, some >= 2^30): 32-bit residues again, but 4q no longer fits a word:
+//         forward values in [0,2q), inverse values canonical, two conditional subtractions per
+//         butterfly (10 instructions against 8 for AR = 2 and ~25 for AR = 1).  Covers the rest
+//         of the reference's correct domain (goodQs above 2^30, e.g. 1073872897, 2148249601 is out).
 //  AR = 1 (every q_t < 2^61): 64-bit residues, Shoup products with the 9-multiply approximate
 //         quotient (shoup_acc, result in [0,4q)); forward values in [0,8q), inverse in [0,4q).
 //  AR = 0 (2^61 <= q_t < 2^62): 10-multiply exact quotient, ranges [0,4q) / [0,2q).
-template <int AR> using VT = std::conditional_t<AR == 2, u32, u64>;
+template <int AR> using VT = std::conditional_t<AR >= 2, u32, u64>;
 
 // Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
 struct QK {
@@ -154,7 +158,7 @@ struct QK32 {
   u32 q, q2;
   __device__ __forceinline__ explicit QK32(u64 q_) : q((u32)q_), q2(2 * (u32)q_) {}
 };
-template <int AR> using QKT = std::conditional_t<AR == 2, QK32, QK>;
+template <int AR> using QKT = std::conditional_t<AR >= 2, QK32, QK>;
 
 __device__ __forceinline__ u32 csub32(u32 x, u32 m) { return min(x, x - m); }        // x < 2m
 // w*y mod q in [0,2q) for any 32-bit y
@@ -163,7 +167,12 @@ __device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return w *
 // forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
 template <int AR>
 __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
+  if constexpr (AR == 3) {
+    const u32 x = csub32(X, k.q);                     // [0,2q) -> [0,q)
+    const u32 t = csub32(shoup32(Y, w, wp, k.q), k.q);
+    X = x + t;                                        // [0,2q)
+    Y = x - t + k.q;                                  // (0,2q)
+  } else if constexpr (AR == 2) {
     const u32 x = csub32(X, k.q2);                    // [0,4q) -> [0,2q)
     const u32 t = shoup32(Y, w, wp, k.q);
     X = x + t;
@@ -184,7 +193,12 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
 // inverse (Gentleman-Sande) butterfly:  X' = X + Y,  Y' = (X - Y) * w
 template <int AR>
 __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
+  if constexpr (AR == 3) {                            // canonical in, canonical out
+    const u32 s = X + Y;
+    const u32 d = X - Y + k.q;
+    X = csub32(s, k.q);
+    Y = csub32(shoup32(d, w, wp, k.q), k.q);
+  } else if constexpr (AR == 2) {
     const u32 s = X + Y;
     const u32 d = X - Y + k.q2;
     X = csub32(s, k.q2);
@@ -205,7 +219,12 @@ __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
 // (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
 template <int AR>
 __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, VT<AR> s0, VT<AR> s1, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
+  if constexpr (AR == 3) {
+    const u32 s = X + Y;
+    const u32 d = X - Y + k.q;
+    X = csub32(shoup32(s, s0, s1, k.q), k.q);
+    Y = csub32(shoup32(d, w, wp, k.q), k.q);
+  } else if constexpr (AR == 2) {
     const u32 s = X + Y;
     const u32 d = X - Y + k.q2;
     X = shoup32(s, s0, s1, k.q);
@@ -223,14 +242,16 @@ __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT
   }
 }
 template <int AR> __device__ __forceinline__ VT<AR> canon_fwd(VT<AR> v, const QKT<AR>& k) {
-  if constexpr (AR == 2) return csub32(csub32(v, k.q2), k.q);
+  if constexpr (AR == 3) return csub32(v, k.q);
+  else if constexpr (AR == 2) return csub32(csub32(v, k.q2), k.q);
   else {
     if constexpr (AR == 1) v = csubn(v, k.nq4);
     return csubn(csubn(v, k.nq2), k.nq);
   }
 }
 template <int AR> __device__ __forceinline__ VT<AR> canon_inv(VT<AR> v, const QKT<AR>& k) {
-  if constexpr (AR == 2) return csub32(v, k.q);
+  if constexpr (AR == 3) return v;
+  else if constexpr (AR == 2) return csub32(v, k.q);
   else {
     if constexpr (AR == 1) v = csubn(v, k.nq2);
     return csubn(v, k.nq);
@@ -238,14 +259,14 @@ template <int AR> __device__ __forceinline__ VT<AR> canon_inv(VT<AR> v, const QK
 }
 // reference-style input in (-q, q) -> [0, q)
 template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR>& k) {
-  if constexpr (AR == 2) return (u32)x + (k.q & (u32)(x >> 63));
+  if constexpr (AR >= 2) return (u32)x + (k.q & (u32)(x >> 63));
   else return canon_in(x, k.q);
 }
 // pointwise product of a canonical a-hat and a lazy b-hat (forward range), any range the
 // inverse transform accepts
 template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, const ModCtx& mc, const QKT<AR>& k) {
-  if constexpr (AR == 2) {
-    const u64 x = (u64)a * b;                          // < q * 4q < 2^62
+  if constexpr (AR >= 2) {
+    const u64 x = (u64)a * b;                          // < q * 4q < 2^62 (AR = 2), q * 2q < 2^63 (AR = 3)
     const u64 Q = __umul64hi(x, mc.mu);                // floor(x/q) or one less
     return csub32((u32)(x - Q * mc.q), k.q);           // [0,2q) -> [0,q)
   } else if constexpr (AR == 1) {
@@ -696,7 +717,7 @@ constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)
 // holds several short polynomials — the per-modulus constants stay in SGPRs (instantiated for
 // n <= 512 only; longer polynomials own whole waves and are uniform anyway)
 template <int L, int MODE, int AR, bool TU = false>
-__global__ void __launch_bounds__(pow2_threads(L), AR == 2 ? 8 : 4)
+__global__ void __launch_bounds__(pow2_threads(L), AR >= 2 ? 8 : 4)
 k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
        const VT<AR>* __restrict__ tw_fwd, const VT<AR>* __restrict__ tw_inv, const VT<AR>* __restrict__ scale,
        const ModCtx* __restrict__ mod, int xcd_map) {
@@ -846,7 +867,7 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if constexpr (NT < 64 && AR != 2) {
+  if constexpr (NT < 64 && AR < 2) {
     if (a.T == 1) {
       hipLaunchKernelGGL((k_pow2<L, MODE, AR, true>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
                          a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),

@@ -342,7 +342,8 @@ def test_extreme_values_and_moduli(gpu, cpuref):
 @pytest.mark.parametrize("m", [2 ** 5, 2 ** 10, 2 ** 12, 2 ** 14])
 def test_arithmetic_class_boundaries(gpu, cpuref, m):
     """The m = 2^k path picks its arithmetic per plan: 32-bit residues when every modulus is
-    below 2^30, 64-bit lazy Shoup below 2^61, exact above.  Moduli hugging each boundary, the
+    below 2^30 (lazy ranges) or below 2^31 (tighter ranges), 64-bit lazy Shoup below 2^61,
+    exact above.  Moduli hugging each boundary, the
     extreme residues, and tuples that mix classes (the widest class must win)."""
     pps = lm.factor_pps(m)
 
@@ -352,14 +353,16 @@ def test_arithmetic_class_boundaries(gpu, cpuref, m):
             q -= m
         return q
 
-    q_lo = last_good_below(2 ** 30)            # largest 32-bit-class modulus
-    q_mid = lm.first_good_q(m, 2 ** 30)        # smallest 64-bit-class modulus
+    q_lo = last_good_below(2 ** 30)            # largest modulus of the lazy 32-bit class
+    q_mid = lm.first_good_q(m, 2 ** 30)        # smallest modulus of the second 32-bit class
+    q_31 = last_good_below(2 ** 31)            # largest 32-bit modulus
+    q_31h = lm.first_good_q(m, 2 ** 31)        # smallest modulus that needs 64-bit residues
     q_hi = last_good_below(2 ** 61)            # largest lazy-class modulus
     q_top = lm.first_good_q(m, 2 ** 61)        # smallest exact-class modulus
-    assert q_lo < 2 ** 30 < q_mid and q_hi < 2 ** 61 < q_top
+    assert q_lo < 2 ** 30 < q_mid < q_31 < 2 ** 31 < q_31h and q_hi < 2 ** 61 < q_top
     rng = np.random.default_rng(m)
-    for qs in ([q_lo], [q_mid], [q_hi], [q_top], [q_lo, 12289 if m <= 4096 else 65537],
-               [q_lo, q_mid], [q_mid, q_hi, q_lo], [q_top, q_lo]):
+    for qs in ([q_lo], [q_mid], [q_31], [q_31h], [q_hi], [q_top], [q_lo, 12289 if m <= 4096 else 65537],
+               [q_lo, q_mid], [q_31, q_lo, q_mid], [q_31, q_31h], [q_mid, q_hi, q_lo], [q_top, q_lo]):
         P, R = gpu.Plan(pps, qs), Params(pps, qs)
         y, z = R.random(rng, 3), R.random(rng, 3)
         for t, q in enumerate(qs):                 # extreme residues in two of the polynomials
