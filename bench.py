@@ -121,6 +121,11 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
     y.copy_(x)
     ms = timed(lambda: p30.crt(y, stream=stream.cuda_stream))
     out["crt_30bit"] = {"ms": round(ms, 4), "GBps": round(2 * slab / ms / 1e6, 1)}
+    q31 = 1073872897            # config 2's CT-valid modulus: just above 2^30
+    p31 = lol_amd.Plan([(2, 14)], [q31])
+    x, x2 = a % q31, (a + 1) % q31
+    ms = timed(lambda: p31.polymul(x, x2, out=y, stream=stream.cuda_stream))
+    out["polymul_31bit"] = {"ms": round(ms, 4), "poly_muls_per_s": round(B / ms * 1e3, 1), "GBps": round(3 * slab / ms / 1e6, 1), "q": q31}
     return out
 
 
