@@ -475,6 +475,60 @@ def test_config2_full_batch(gpu, cpuref):
     # checksum of checksums against the sampled oracle rows is covered above; sortedness n/a
 
 
+def test_concurrent_host_threads(gpu, cpuref):
+    """The reference is non-reentrant (process-global modulus, types.h:59).  Here four host
+    threads drive their own plans (different rings and moduli, one of them the mixed-radix path
+    with its plan-owned work buffer) on their own streams at the same time, and two more share
+    ONE plan through the drop-in-style host calls; every result must be the oracle's."""
+    import threading
+    torch = pytest.importorskip("torch")
+    jobs = [(2 ** 12, 2 ** 60), (2 ** 10, 2 ** 29), (45, 2 ** 58), (2 ** 8 * 3, 2 ** 30)]
+    errors = []
+
+    def own_plan(m, lower, seed):
+        try:
+            pps = lm.factor_pps(m)
+            qs = [lm.first_good_q(m, lower), lm.first_good_q(m, lower * 2)]
+            P, R = gpu.Plan(pps, qs), Params(pps, qs)
+            rng = np.random.default_rng(seed)
+            st = torch.cuda.Stream()
+            for _ in range(6):
+                a, b = R.random(rng, 7), R.random(rng, 7)
+                da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+                dc = torch.empty_like(da)
+                with torch.cuda.stream(st):
+                    P.polymul(da, db, out=dc, stream=st.cuda_stream)
+                    P.crt(da, stream=st.cuda_stream)
+                st.synchronize()
+                if not np.array_equal(dc.cpu().numpy(), cpuref.polymul(R, a, b).reshape(a.shape)):
+                    errors.append(("polymul", m))
+                if not np.array_equal(da.cpu().numpy(), cpuref.crt(R, a).reshape(a.shape)):
+                    errors.append(("crt", m))
+        except Exception as ex:      # noqa: BLE001
+            errors.append((type(ex).__name__, str(ex), m))
+
+    shared_pps, shared_qs = [(2, 9)], [lm.first_good_q(512, 2 ** 40)]
+    PS, RS = gpu.Plan(shared_pps, shared_qs), Params(shared_pps, shared_qs)
+
+    def shared_plan(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(6):
+                a = RS.random(rng, 3)
+                if not np.array_equal(PS.crtInv(PS.crt(a)), a):      # numpy in/out: host round trips
+                    errors.append(("shared", seed))
+        except Exception as ex:      # noqa: BLE001
+            errors.append((type(ex).__name__, str(ex)))
+
+    threads = [threading.Thread(target=own_plan, args=(m, lo, i)) for i, (m, lo) in enumerate(jobs)]
+    threads += [threading.Thread(target=shared_plan, args=(100 + i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_slabs_larger_than_4GiB(gpu, cpuref):
     """70,000 polynomials of n = 8192: 4.6 GB per operand, past every 32-bit byte offset.  The
     m = 2^k kernels address through per-workgroup buffer windows, the streaming kernels with
