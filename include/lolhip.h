@@ -4,7 +4,7 @@
  *
  * Two groups of entry points:
  *
- *  (A) DROP-IN SYMBOLS: the ten `extern "C"` functions lol-cpp exports for Z_q and
+ *  (A) DROP-IN SYMBOLS: the nine `extern "C"` functions lol-cpp exports for Z_q and
  *      that lol-cpp's Haskell shim binds with `foreign import ccall unsafe`
  *      (lol-cpp/Crypto/Lol/Cyclotomic/Tensor/CPP/Backend.hs:304-337).  Same names,
  *      same argument order and meaning, host pointers, in place, one polynomial
@@ -21,8 +21,11 @@
  *   int64, n = totient(m), T = tupSize.  Inputs may be in (-q_t, q_t); outputs are
  *   always canonical in [0, q_t) (zq.cpp:57-68).
  *
- * All functions are re-entrant (no global modulus, cf. types.h:59) and never call
- * exit() (cf. ASSERT, types.h:36-41): errors come back as status codes.
+ * All functions are re-entrant (no global modulus, cf. types.h:59): any number of host threads may
+ * call into one plan concurrently, on the same or on different streams; per-call workspaces are
+ * stream-ordered allocations or caller-provided.  A plan belongs to the HIP device that was
+ * current when it was created; calling it with another device current returns LOLHIP_ERR_DEVICE.
+ * Nothing calls exit() (cf. ASSERT, types.h:36-41): errors come back as status codes.
  * There is NO CPU fallback: without a usable GPU every compute entry point
  * returns LOLHIP_ERR_NO_DEVICE.
  */
@@ -48,7 +51,8 @@ enum {
   LOLHIP_ERR_ROOT = -4,         /* caller-supplied root of unity has the wrong order      */
   LOLHIP_ERR_NO_DEVICE = -5,    /* no HIP device: compute entry points refuse to run      */
   LOLHIP_ERR_HIP = -6,          /* HIP runtime error                                      */
-  LOLHIP_ERR_NOT_DIVISIBLE = -7 /* divG: oddRad(m) not invertible mod some q_t            */
+  LOLHIP_ERR_NOT_DIVISIBLE = -7,/* divG: oddRad(m) not invertible mod some q_t            */
+  LOLHIP_ERR_DEVICE = -8        /* the calling thread's current HIP device is not the one the plan's tables live on */
 };
 
 /* ------------------------------------------------------------------------- */
@@ -227,6 +231,12 @@ enum {
   LOLHIP_EXT_EMBED_DEC = 3, LOLHIP_EXT_EMBED_CRT = 4, LOLHIP_EXT_COEFFS = 5
 };
 LOLHIP_API int lolhip_ext_host(const lolhip_ext *x, int op, int64_t *out, const int64_t *in, int64_t B);
+/* The host-pointer calls (and the drop-in symbols, which go through them) keep per host thread and
+ * device one stream, a pinned staging area and two device buffers, grown on demand: the steady
+ * state of a call is memcpy, H2D, kernels, D2H and a wait on that thread's stream — no allocation,
+ * no device-wide synchronisation.  This frees the calling thread's set (optional; e.g. before a
+ * worker thread exits). */
+LOLHIP_API void lolhip_thread_release(void);
 
 /* --- wire format: Lol's protobuf ring elements, host side -------
  * message Rq { uint32 m = 1; uint64 q = 2; repeated sint64 xs = 3; }   (lol/Lol.proto)

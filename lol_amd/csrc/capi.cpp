@@ -62,15 +62,35 @@ int make_plan(const lolhip_pp* pps, int npps, const int64_t* qs, int T, const in
 int need_device(const lolhip_plan* p) {
   if (!p) return LOLHIP_ERR_INVALID;
   if (!p->P.device) return LOLHIP_ERR_NO_DEVICE;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return LOLHIP_ERR_HIP;
+  if (dev != p->P.device_id) return LOLHIP_ERR_DEVICE;     // the plan's tables live on another GPU
   return LOLHIP_OK;
 }
+
+// stream-ordered workspace: allocated and released on the caller's stream, so concurrent calls on
+// one plan (other host threads, other streams) never share it and nothing synchronises the device
+struct StreamBuf {
+  void* p = nullptr;
+  hipStream_t s;
+  explicit StreamBuf(hipStream_t s_) : s(s_) {}
+  ~StreamBuf() { if (p) (void)hipFreeAsync(p, s); }
+  bool alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, s) == hipSuccess; }
+};
 
 int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, int64_t B, const int64_t* src = nullptr) {
   GenericLaunch a;
   a.stream = s; a.y = y; a.src = src; a.B = B; a.T = P.T; a.n = P.n;
   a.stages = sp.d_stages; a.nstages = sp.nstages;
   a.consts = P.d_consts; a.cpc = P.consts_per_comp; a.mod = P.d_mod;
-  a.scratch = P.d_scratch; a.scratch_bytes = P.scratch_bytes;
+  StreamBuf ring(s);
+  a.scratch = nullptr; a.scratch_bytes = 0;
+  if (P.needs_scratch && B > 0) {       // one ping-pong pair per resident workgroup, at most 512 of them
+    const i64 groups = B * P.T < 512 ? B * P.T : 512;
+    a.scratch_bytes = (size_t)groups * 2 * (size_t)P.n * sizeof(u64);
+    if (!ring.alloc(a.scratch_bytes)) return LOLHIP_ERR_HIP;
+    a.scratch = (u64*)ring.p;
+  }
   a.vec_ok = !getenv("LOLHIP_GENERIC_SCALAR");
   for (const Stage& st : sp.stages)
     if (st.kind != ST_DIAG && st.kind != ST_SCALE &&
@@ -199,19 +219,13 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
   if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
-  // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp
-  // lives in the plan and only grows (no allocation or sync on the steady-state path; calls on
-  // one plan must be stream-ordered, as with any workspace).
+  // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp is a
+  // stream-ordered allocation of this call (the pool recycles it: no device synchronisation).
   const size_t bytes = sizeof(int64_t) * (size_t)(B * P.n * P.T);
   if (bytes == 0) return LOLHIP_OK;
-  if (P.tmp_bytes < bytes) {
-    if (hipDeviceSynchronize() != hipSuccess) return LOLHIP_ERR_HIP;
-    if (P.d_tmp) (void)hipFree(P.d_tmp);
-    P.d_tmp = nullptr; P.tmp_bytes = 0;
-    if (hipMalloc((void**)&P.d_tmp, bytes) != hipSuccess) return LOLHIP_ERR_HIP;
-    P.tmp_bytes = bytes;
-  }
-  int64_t* tmp = P.d_tmp;
+  StreamBuf tmpbuf(s);
+  if (!tmpbuf.alloc(bytes)) return LOLHIP_ERR_HIP;
+  int64_t* tmp = (int64_t*)tmpbuf.p;
   rc = LOLHIP_OK;
   if (!P.pow2_part || getenv("LOLHIP_NO_POW2_PART")) {
     // stage program alone: transform b into the temp first (c may alias b), then a into c
@@ -527,42 +541,109 @@ int lolhip_twace_crt_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const 
 
 // ---- host-pointer convenience ----------------------------------------------------------
 
-struct DevBuf {
-  int64_t* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  bool alloc(size_t bytes) { return hipMalloc((void**)&p, bytes ? bytes : 8) == hipSuccess; }
+}  // extern "C"
+
+namespace {
+
+// Per host thread and device: one stream, one pinned staging area and two device buffers, grown on
+// demand and kept — the steady state of a host-pointer call is memcpy -> H2D -> kernels -> D2H ->
+// hipStreamSynchronize on the thread's own stream: no hipMalloc/hipFree, no device-wide
+// synchronisation, nothing shared with other threads (what the reference's callers need:
+// CPP.hs:325-337 thaws a fresh vector and calls one tensor*Rq per ring operation).
+struct HostStage {
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  char* pinned = nullptr; size_t pinned_bytes = 0;
+  char* d[2] = {nullptr, nullptr}; size_t d_bytes[2] = {0, 0};
+  bool grow_pinned(size_t bytes) {
+    if (bytes <= pinned_bytes) return true;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr; pinned_bytes = 0;
+    size_t cap = 1 << 16;
+    while (cap < bytes) cap <<= 1;
+    if (hipHostMalloc((void**)&pinned, cap, hipHostMallocDefault) != hipSuccess) return false;
+    pinned_bytes = cap;
+    return true;
+  }
+  bool grow_dev(int i, size_t bytes) {
+    if (bytes <= d_bytes[i]) return true;
+    if (stream && hipStreamSynchronize(stream) != hipSuccess) return false;
+    if (d[i]) (void)hipFree(d[i]);
+    d[i] = nullptr; d_bytes[i] = 0;
+    size_t cap = 1 << 16;
+    while (cap < bytes) cap <<= 1;
+    if (hipMalloc((void**)&d[i], cap) != hipSuccess) return false;
+    d_bytes[i] = cap;
+    return true;
+  }
+  void release() {
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (pinned) (void)hipHostFree(pinned);
+    for (char* q : d) if (q) (void)hipFree(q);
+    *this = HostStage();
+  }
 };
+thread_local std::vector<HostStage> g_stage;     // one entry per device this thread has used
+
+HostStage* host_stage() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (HostStage& h : g_stage) if (h.dev == dev) return &h;
+  HostStage h;
+  h.dev = dev;
+  if (hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  g_stage.push_back(h);
+  return &g_stage.back();
+}
+
+}  // namespace
+
+extern "C" {
+
+void lolhip_thread_release(void) {
+  for (HostStage& h : g_stage) h.release();
+  g_stage.clear();
+}
 
 int lolhip_op_host(const lolhip_plan* p, int op, int64_t* y, const int64_t* b, int64_t B) {
   int rc = need_device(p); if (rc) return rc;
   if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
   if ((op == LOLHIP_OP_DIVGPOW || op == LOLHIP_OP_DIVGDEC) && !divg_ok(p->P)) return LOLHIP_ERR_NOT_DIVISIBLE;
+  if (op < LOLHIP_OP_CRT || op > LOLHIP_OP_DIVGCRT) return LOLHIP_ERR_INVALID;
   const size_t bytes = sizeof(int64_t) * (size_t)(B * p->P.n * p->P.T);
   if (bytes == 0) return LOLHIP_OK;
   const bool two = (op == LOLHIP_OP_MUL || op == LOLHIP_OP_POLYMUL);
   if (two && !b) return LOLHIP_ERR_INVALID;
-  DevBuf dy, db;
-  if (!dy.alloc(bytes) || (two && !db.alloc(bytes))) return LOLHIP_ERR_HIP;
-  if (hipMemcpy(dy.p, y, bytes, hipMemcpyHostToDevice) != hipSuccess) return LOLHIP_ERR_HIP;
-  if (two && hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice) != hipSuccess) return LOLHIP_ERR_HIP;
-  switch (op) {
-    case LOLHIP_OP_CRT: rc = lolhip_crt_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_CRTINV: rc = lolhip_crtinv_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_MUL: rc = lolhip_mul_batch(p, nullptr, dy.p, db.p, B); break;
-    case LOLHIP_OP_POLYMUL: rc = lolhip_polymul_batch(p, nullptr, dy.p, dy.p, db.p, B); break;
-    case LOLHIP_OP_L: rc = lolhip_l_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_LINV: rc = lolhip_linv_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_MULGPOW: rc = lolhip_mulgpow_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_MULGDEC: rc = lolhip_mulgdec_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_DIVGPOW: rc = lolhip_divgpow_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_DIVGDEC: rc = lolhip_divgdec_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_MULGCRT: rc = lolhip_mulgcrt_batch(p, nullptr, dy.p, B); break;
-    case LOLHIP_OP_DIVGCRT: rc = lolhip_divgcrt_batch(p, nullptr, dy.p, B); break;
-    default: return LOLHIP_ERR_INVALID;
+  HostStage* h = host_stage();
+  if (!h) return LOLHIP_ERR_HIP;
+  if (!h->grow_pinned(two ? 2 * bytes : bytes) || !h->grow_dev(0, bytes) || (two && !h->grow_dev(1, bytes))) return LOLHIP_ERR_HIP;
+  hipStream_t s = h->stream;
+  int64_t* dy = (int64_t*)h->d[0];
+  int64_t* db = (int64_t*)h->d[1];
+  std::memcpy(h->pinned, y, bytes);
+  if (hipMemcpyAsync(dy, h->pinned, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
+  if (two) {
+    std::memcpy(h->pinned + bytes, b, bytes);
+    if (hipMemcpyAsync(db, h->pinned + bytes, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
   }
+  switch (op) {
+    case LOLHIP_OP_CRT: rc = lolhip_crt_batch(p, s, dy, B); break;
+    case LOLHIP_OP_CRTINV: rc = lolhip_crtinv_batch(p, s, dy, B); break;
+    case LOLHIP_OP_MUL: rc = lolhip_mul_batch(p, s, dy, db, B); break;
+    case LOLHIP_OP_POLYMUL: rc = lolhip_polymul_batch(p, s, dy, dy, db, B); break;
+    case LOLHIP_OP_L: rc = lolhip_l_batch(p, s, dy, B); break;
+    case LOLHIP_OP_LINV: rc = lolhip_linv_batch(p, s, dy, B); break;
+    case LOLHIP_OP_MULGPOW: rc = lolhip_mulgpow_batch(p, s, dy, B); break;
+    case LOLHIP_OP_MULGDEC: rc = lolhip_mulgdec_batch(p, s, dy, B); break;
+    case LOLHIP_OP_DIVGPOW: rc = lolhip_divgpow_batch(p, s, dy, B); break;
+    case LOLHIP_OP_DIVGDEC: rc = lolhip_divgdec_batch(p, s, dy, B); break;
+    case LOLHIP_OP_MULGCRT: rc = lolhip_mulgcrt_batch(p, s, dy, B); break;
+    default: rc = lolhip_divgcrt_batch(p, s, dy, B); break;
+  }
+  if (!rc && hipMemcpyAsync(h->pinned, dy, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) return LOLHIP_ERR_HIP;   // also on error: nothing of ours stays in flight
   if (rc) return rc;
-  if (hipDeviceSynchronize() != hipSuccess) return LOLHIP_ERR_HIP;
-  if (hipMemcpy(y, dy.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return LOLHIP_ERR_HIP;
+  std::memcpy(y, h->pinned, bytes);
   return LOLHIP_OK;
 }
 
@@ -575,22 +656,28 @@ int lolhip_ext_host(const lolhip_ext* x, int op, int64_t* out, const int64_t* in
   const size_t bin = sizeof(int64_t) * (size_t)(B * (to_hi ? x->X.host.phi : x->X.host.phi2) * T);
   const size_t bout = sizeof(int64_t) * (size_t)(B * ((to_hi || op == LOLHIP_EXT_COEFFS) ? x->X.host.phi2 : x->X.host.phi) * T);
   if (bout == 0) return LOLHIP_OK;
-  DevBuf di, dout;
-  if (!di.alloc(bin) || !dout.alloc(bout)) return LOLHIP_ERR_HIP;
-  if (hipMemcpy(di.p, in, bin, hipMemcpyHostToDevice) != hipSuccess) return LOLHIP_ERR_HIP;
+  HostStage* h = host_stage();
+  if (!h) return LOLHIP_ERR_HIP;
+  if (!h->grow_pinned(bin > bout ? bin : bout) || !h->grow_dev(0, bin) || !h->grow_dev(1, bout)) return LOLHIP_ERR_HIP;
+  hipStream_t s = h->stream;
+  int64_t* di = (int64_t*)h->d[0];
+  int64_t* dout = (int64_t*)h->d[1];
+  std::memcpy(h->pinned, in, bin);
+  if (hipMemcpyAsync(di, h->pinned, bin, hipMemcpyHostToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
   int rc;
   switch (op) {
-    case LOLHIP_EXT_TWACE_POWDEC: rc = lolhip_twace_powdec_batch(x, nullptr, dout.p, di.p, B); break;
-    case LOLHIP_EXT_TWACE_CRT: rc = lolhip_twace_crt_batch(x, nullptr, dout.p, di.p, B); break;
-    case LOLHIP_EXT_EMBED_POW: rc = lolhip_embed_pow_batch(x, nullptr, dout.p, di.p, B); break;
-    case LOLHIP_EXT_EMBED_DEC: rc = lolhip_embed_dec_batch(x, nullptr, dout.p, di.p, B); break;
-    case LOLHIP_EXT_EMBED_CRT: rc = lolhip_embed_crt_batch(x, nullptr, dout.p, di.p, B); break;
-    case LOLHIP_EXT_COEFFS: rc = lolhip_coeffs_batch(x, nullptr, dout.p, di.p, B); break;
+    case LOLHIP_EXT_TWACE_POWDEC: rc = lolhip_twace_powdec_batch(x, s, dout, di, B); break;
+    case LOLHIP_EXT_TWACE_CRT: rc = lolhip_twace_crt_batch(x, s, dout, di, B); break;
+    case LOLHIP_EXT_EMBED_POW: rc = lolhip_embed_pow_batch(x, s, dout, di, B); break;
+    case LOLHIP_EXT_EMBED_DEC: rc = lolhip_embed_dec_batch(x, s, dout, di, B); break;
+    case LOLHIP_EXT_EMBED_CRT: rc = lolhip_embed_crt_batch(x, s, dout, di, B); break;
+    case LOLHIP_EXT_COEFFS: rc = lolhip_coeffs_batch(x, s, dout, di, B); break;
     default: return LOLHIP_ERR_INVALID;
   }
+  if (!rc && hipMemcpyAsync(h->pinned, dout, bout, hipMemcpyDeviceToHost, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) return LOLHIP_ERR_HIP;
   if (rc) return rc;
-  if (hipDeviceSynchronize() != hipSuccess) return LOLHIP_ERR_HIP;
-  if (hipMemcpy(out, dout.p, bout, hipMemcpyDeviceToHost) != hipSuccess) return LOLHIP_ERR_HIP;
+  std::memcpy(out, h->pinned, bout);
   return LOLHIP_OK;
 }
 

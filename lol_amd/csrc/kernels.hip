@@ -159,8 +159,9 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const u32 eo = (u32)lay_tab<LFIN>.xr[e] * uT8;
-        const u32 h0 = (u32)load_u64(rh, off_h, hoff + eo);
-        const u32 h1 = (u32)load_u64(rh, off_h, hoff + hstride + eo);
+        // hint residues may be any representative in (-q_s, q_s), like every other input
+        const u32 h0 = from_i64<AR>((i64)load_u64(rh, off_h, hoff + eo), qk);
+        const u32 h1 = from_i64<AR>((i64)load_u64(rh, off_h, hoff + hstride + eo), qk);
         const u32 vc = canon_fwd<AR>(v[e], qk);                        // [0,4q) -> [0,q)
         acc0[e] += (u64)h0 * vc;
         acc1[e] += (u64)h1 * vc;
@@ -195,12 +196,13 @@ static hipError_t launch_keyswitch_L(const KeySwitchLaunch& a) {
   const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
   const i64 grid = (items + PPW - 1) / PPW;
   if (grid == 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<L>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (lds_bytes > 64 * 1024) {
+    static KernelDev tab[MAX_DEV];
+    hipError_t e = kernel_dev_setup(tab, [&]() -> hipError_t {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<L>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_keyswitch<L>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream, a.c2, a.hint,
                      a.addend, a.out, a.B, a.T, a.tw_fwd32, a.mod, a.dp, a.magic32, xcd_map);
@@ -578,16 +580,16 @@ hipError_t launch_generic(const GenericLaunch& a) {
     const i64 ngroups = (a.B + ppw - 1) / ppw;
     grid = ngroups * a.T;
     if (grid > 65536) grid = 65536;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, false>),
+    static KernelDev tab[MAX_DEV];
+    hipError_t e = kernel_dev_setup(tab, [&]() -> hipError_t {
+      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, true>),
+      if (r == hipSuccess)
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+      return r;
+    });
+    if (e != hipSuccess) return e;
     // a workgroup that fills a CU's LDS on its own should also fill its SIMDs
     const int threads = ((size_t)ppw * a.n >= 4096) ? 1024 : ((size_t)ppw * a.n >= 1024 ? 512 : 256);
     if (a.q32)

@@ -383,25 +383,23 @@ int plan_upload(Plan& P) {
       if ((rc = upload(&P.pow2.d_scale32, s32))) return rc;
     }
   }
-  // polynomials too large for the LDS ping-pong run the generic path out of HBM scratch
-  if (2 * (size_t)P.n * sizeof(u64) > 152 * 1024) {
-    P.scratch_bytes = (size_t)512 * 2 * (size_t)P.n * sizeof(u64);
-    HIPCK(hipMalloc((void**)&P.d_scratch, P.scratch_bytes));
-  }
+  // polynomials too large for the LDS ping-pong run the generic path out of an HBM scratch ring
+  // (allocated per call, stream-ordered: run_prog in capi.cpp)
+  P.needs_scratch = 2 * (size_t)P.n * sizeof(u64) > 152 * 1024;
+  HIPCK(hipGetDevice(&P.device_id));
   P.device = true;
   return LOLHIP_OK;
 }
 
 void plan_free_device(Plan& P) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_scratch); fr(P.d_tmp);
-  P.d_tmp = nullptr; P.tmp_bytes = 0;
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt);
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
                            &P.prog_crt_odd, &P.prog_crtinv_odd};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
-  P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr; P.d_scratch = nullptr;
+  P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr;
   P.pow2 = Pow2Tables();
   P.device = false;
 }

@@ -94,10 +94,11 @@ struct Plan {
   i64* d_ginvcrt = nullptr;                 // [n*T]
   Pow2Tables pow2;
   bool is_pow2 = false;
-  mutable i64* d_tmp = nullptr;             // operand copy for the unfused (generic-m) poly-mul, grown on demand
-  mutable size_t tmp_bytes = 0;
-  u64* d_scratch = nullptr;                 // ping-pong space for polynomials too large for LDS
-  size_t scratch_bytes = 0;
+  int device_id = -1;                       // HIP device the tables were uploaded to
+  // Nothing in a plan is written after plan_upload(): per-call workspaces (the operand copy of the
+  // unfused poly-mul, the HBM ping-pong ring of polynomials too large for LDS) are stream-ordered
+  // allocations made by the call that needs them, so host threads and streams can share a plan.
+  bool needs_scratch = false;               // 2 * n * 8 B exceeds the LDS ping-pong budget
 };
 
 // ring-extension plan for m | m'

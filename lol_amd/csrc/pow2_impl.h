@@ -5,7 +5,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -849,6 +851,30 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   }
 }
 
+// Per-device launch state of one kernel instantiation.  hipFuncSetAttribute is per DEVICE: a
+// process that drives several GPUs has to repeat it on each of them (a per-process flag made the
+// second GPU's first > 64 KiB-LDS launch fail).  state 0 = not set up, 2 = ready.
+constexpr int MAX_DEV = 64;
+struct KernelDev { std::atomic<int> state{0}; };
+inline std::mutex& kernel_dev_mutex() { static std::mutex m; return m; }
+template <typename Setup>
+static hipError_t kernel_dev_setup(KernelDev (&tab)[MAX_DEV], Setup&& setup) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+  KernelDev& d = tab[dev];
+  if (d.state.load(std::memory_order_acquire) != 2) {
+    std::lock_guard<std::mutex> g(kernel_dev_mutex());
+    if (d.state.load(std::memory_order_relaxed) != 2) {
+      e = setup();
+      if (e != hipSuccess) return e;
+      d.state.store(2, std::memory_order_release);
+    }
+  }
+  return hipSuccess;
+}
+
 template <int L, int MODE, int AR>
 static hipError_t launch_pow2_L(const Pow2Launch& a) {
   constexpr int n = 1 << L;
@@ -860,12 +886,17 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
   const int xcd_map = (a.T > 1 && PPW == 1 && a.B % 8 == 0) ? 1 : 0;
   const i64 grid = (items + PPW - 1) / PPW;
   if (grid == 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (lds_bytes > 64 * 1024) {
+    static KernelDev tab[MAX_DEV];
+    hipError_t e = kernel_dev_setup(tab, [&]() -> hipError_t {
+      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (r == hipSuccess && NT < 64 && AR < 2)
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      return r;
+    });
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   if constexpr (NT < 64 && AR < 2) {
     if (a.T == 1) {

@@ -25,11 +25,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
 
-OK, ERR_INVALID, ERR_MODULUS, ERR_NO_CRT, ERR_ROOT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_DIVISIBLE = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_INVALID, ERR_MODULUS, ERR_NO_CRT, ERR_ROOT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_DIVISIBLE, ERR_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7, -8
 _ERRNAMES = {ERR_INVALID: "invalid argument", ERR_MODULUS: "modulus out of range / missing inverse",
              ERR_NO_CRT: "no CRT basis for this modulus", ERR_ROOT: "bad root of unity",
              ERR_NO_DEVICE: "no HIP device (liblolhip has no CPU fallback)", ERR_HIP: "HIP runtime error",
-             ERR_NOT_DIVISIBLE: "not divisible by g"}
+             ERR_NOT_DIVISIBLE: "not divisible by g",
+             ERR_DEVICE: "the current HIP device is not the plan's device"}
 
 OP_CRT, OP_CRTINV, OP_MUL, OP_POLYMUL, OP_L, OP_LINV, OP_MULGPOW, OP_MULGDEC, OP_DIVGPOW, OP_DIVGDEC, OP_MULGCRT, OP_DIVGCRT = range(12)
 EXT_TWACE_POWDEC, EXT_TWACE_CRT, EXT_EMBED_POW, EXT_EMBED_DEC, EXT_EMBED_CRT, EXT_COEFFS = range(6)
@@ -110,6 +111,8 @@ def lib():
     L.lolhip_ext_table.restype = i64
     L.lolhip_op_host.argtypes = [vp, ci, _i64p, _i64p, i64]
     L.lolhip_ext_host.argtypes = [vp, ci, _i64p, _i64p, i64]
+    L.lolhip_thread_release.argtypes = []
+    L.lolhip_thread_release.restype = None
     u8p = C.POINTER(C.c_uint8)
     L.lolhip_rqproduct_read.argtypes = [u8p, i64, C.POINTER(C.c_uint32), _i64p, ci, C.POINTER(ci), _i64p, i64]
     L.lolhip_rqproduct_read.restype = i64

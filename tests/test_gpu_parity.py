@@ -520,8 +520,32 @@ def test_concurrent_host_threads(gpu, cpuref):
         except Exception as ex:      # noqa: BLE001
             errors.append((type(ex).__name__, str(ex)))
 
+    # two threads share ONE mixed-radix plan (m = 45) on two streams: its unfused poly-mul needs a
+    # per-call work buffer, which used to live in the plan (a race: use after free, or each
+    # other's operand).  Batch sizes differ so a shared buffer would also have to grow.
+    mix_pps, mix_qs = lm.factor_pps(45), [lm.first_good_q(45, 2 ** 40), lm.first_good_q(45, 2 ** 29)]
+    PM, RM = gpu.Plan(mix_pps, mix_qs), Params(mix_pps, mix_qs)
+
+    def shared_mixed(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            st = torch.cuda.Stream()
+            for it in range(8):
+                B = 5 + 37 * ((seed + it) % 3)
+                a, b = RM.random(rng, B), RM.random(rng, B)
+                da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+                dc = torch.empty_like(da)
+                with torch.cuda.stream(st):
+                    PM.polymul(da, db, out=dc, stream=st.cuda_stream)
+                st.synchronize()
+                if not np.array_equal(dc.cpu().numpy(), cpuref.polymul(RM, a, b).reshape(a.shape)):
+                    errors.append(("shared mixed-radix polymul", seed, it))
+        except Exception as ex:      # noqa: BLE001
+            errors.append((type(ex).__name__, str(ex), "shared mixed"))
+
     threads = [threading.Thread(target=own_plan, args=(m, lo, i)) for i, (m, lo) in enumerate(jobs)]
     threads += [threading.Thread(target=shared_plan, args=(100 + i,)) for i in range(2)]
+    threads += [threading.Thread(target=shared_mixed, args=(200 + i,)) for i in range(2)]
     for t in threads:
         t.start()
     for t in threads:
