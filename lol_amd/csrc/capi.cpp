@@ -78,9 +78,22 @@ struct StreamBuf {
   bool alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, s) == hipSuccess; }
 };
 
+bool use_mixed(const Plan& P, const StageProgram& sp) {
+  static const bool scalar_only = getenv("LOLHIP_GENERIC_SCALAR") != nullptr;       // A/B switch
+  return !scalar_only && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
+}
+
+// y = program(src or y) over B polynomials
 int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, int64_t B, const int64_t* src = nullptr) {
+  if (use_mixed(P, sp)) {
+    MixedLaunch m;
+    m.stream = s; m.y = y; m.a = src ? src : y; m.b = nullptr; m.B = B; m.T = P.T; m.n = P.n;
+    m.st_a = sp.d_stages; m.n_a = sp.nstages; m.st_b = nullptr; m.n_b = 0;
+    m.consts = P.d_consts; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = false;
+    return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+  }
   GenericLaunch a;
-  a.stream = s; a.y = y; a.src = src; a.B = B; a.T = P.T; a.n = P.n;
+  a.stream = s; a.y = y; a.B = B; a.T = P.T; a.n = P.n;
   a.stages = sp.d_stages; a.nstages = sp.nstages;
   a.consts = P.d_consts; a.cpc = P.consts_per_comp; a.mod = P.d_mod;
   StreamBuf ring(s);
@@ -91,16 +104,10 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
     if (!ring.alloc(a.scratch_bytes)) return LOLHIP_ERR_HIP;
     a.scratch = (u64*)ring.p;
   }
-  a.vec_ok = !getenv("LOLHIP_GENERIC_SCALAR");
-  for (const Stage& st : sp.stages)
-    if (st.kind != ST_DIAG && st.kind != ST_SCALE &&
-        !(st.d == 2 || st.d == 3 || st.d == 4 || st.d == 5 || st.d == 6 || st.d == 7 || st.d == 10 || st.d == 11 || st.d == 12 || st.d == 13))
-      a.vec_ok = false;
   a.q32 = true;
   for (u64 q : P.qs) if (q >= ((u64)1 << 32)) a.q32 = false;
-  if (src && !(a.vec_ok && (size_t)a.n * sizeof(u64) <= 64 * 1024)) {     // scalar interpreter: in place only
+  if (src && src != y) {                // the scalar interpreter works in place
     if (hipMemcpyAsync(y, src, sizeof(int64_t) * (size_t)(B * P.n * P.T), hipMemcpyDeviceToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
-    a.src = nullptr;
   }
   return launch_generic(a) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
@@ -219,7 +226,18 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
   if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
-  // generic m: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp is a
+  static const bool unfused = getenv("LOLHIP_POLYMUL_UNFUSED") != nullptr;          // A/B switch
+  const bool split2 = P.pow2_part && !getenv("LOLHIP_NO_POW2_PART");   // the 2-power factor has its own kernels
+  if (!unfused && !split2 && use_mixed(P, P.prog_crt) && use_mixed(P, P.prog_crtinv)) {
+    // one launch: a-hat in registers, b through the same LDS buffer, 3 slab passes (mixed.hip)
+    MixedLaunch m;
+    m.stream = s; m.y = c; m.a = a; m.b = b; m.B = B; m.T = P.T; m.n = P.n;
+    m.st_a = P.prog_crt.d_stages; m.n_a = P.prog_crt.nstages;
+    m.st_b = P.prog_crtinv.d_stages; m.n_b = P.prog_crtinv.nstages;
+    m.consts = P.d_consts; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true;
+    return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+  }
+  // otherwise: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp is a
   // stream-ordered allocation of this call (the pool recycles it: no device synchronisation).
   const size_t bytes = sizeof(int64_t) * (size_t)(B * P.n * P.T);
   if (bytes == 0) return LOLHIP_OK;

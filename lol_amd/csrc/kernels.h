@@ -44,7 +44,6 @@ hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a);
 struct GenericLaunch {
   hipStream_t stream;
   i64* y;
-  const i64* src;    // when non-null and the vector interpreter applies: read from here, write to y
   i64 B;
   int T;
   i64 n;
@@ -56,9 +55,28 @@ struct GenericLaunch {
   u64* scratch;
   size_t scratch_bytes;
   bool q32;          // every modulus < 2^32: 32-bit operand products in the dot-product stages
-  bool vec_ok;       // every stage's vector length is one the vector interpreter instantiates (p <= 13)
 };
 hipError_t launch_generic(const GenericLaunch& a);
+
+// vector-per-thread interpreter + fused mixed-radix poly-mul (mixed.hip); every prime <= 13, n <= 8192
+struct MixedLaunch {
+  hipStream_t stream;
+  i64* y;                // output
+  const i64* a;          // input (may equal y) / first operand
+  const i64* b;          // second operand of the fused poly-mul
+  i64 B;
+  int T;
+  i64 n;
+  const Stage* st_a; int n_a;     // the program, or crt for the fused poly-mul
+  const Stage* st_b; int n_b;     // crtInv for the fused poly-mul
+  const u64* consts;
+  int cpc;
+  const ModCtx* mod;
+  int cls;               // 0: 64-bit residues; 1: every q < 2^32; 2: additionally 13 (q-1)^2 < 2^64
+  bool fused;
+};
+bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T);
+hipError_t launch_mixed(const MixedLaunch& a);
 
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod);
 hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,

@@ -7,8 +7,9 @@
 // (crt.cpp:459-538, tensor.h:76-95).
 //
 //   k_pow2<L,MODE>   m = 2^(L+1): negacyclic NTT (CRT), inverse, fused poly-mul
-//   k_generic        any m: interpreter of the plan's stage program (CRT/CRT^-1 via
-//                    dense p-point stages, L/L^-1, mulG/divG in Pow and Dec bases)
+//   k_generic        any m: scalar interpreter of the plan's stage program — the fallback for
+//                    primes > 13 or n > 8192 (the vector interpreter and the fused mixed-radix
+//                    poly-mul are in mixed.hip)
 //   k_pointwise_mul  mulRq (mul.cpp:14-30) and mulGCRT/divGCRT (CPP.hs:230-231)
 //   k_gather / k_twace_crt   twace*/embed* (Extension.hs:54-129)
 //
@@ -378,174 +379,6 @@ k_generic(i64* __restrict__ y, i64 B, int T, int n, const Stage* __restrict__ st
   }
 }
 
-// -----------------------------------------------------------------------------
-// vector-per-thread interpreter for small primes (d <= 13): one thread owns one d-vector of a
-// stage (I (x) A_p (x) I_rts), reads it from LDS once, applies A_p in registers and writes it
-// back IN PLACE — one LDS buffer instead of ping-pong (more polynomials per CU), one LDS read
-// per coefficient instead of d, matrix entries through scalar loads (they are the same for
-// every vector), and the O(d) forms of L, L^-1, G, G^-1 (l.cpp:28-98, g.cpp:16-123) instead
-// of per-output sums.  Same stage program, same results as k_generic.
-// -----------------------------------------------------------------------------
-template <int D, bool Q32>
-__device__ __forceinline__ void stage_vec(const Stage& st, u64* __restrict__ buf, int vec, int n, u64 n_magic,
-                                          const u64* __restrict__ cst, const ModCtx& mc) {
-  const u64 q = mc.q;
-  const int rts = st.rts;
-  const int blk = fdiv<true>(vec, st.m_rts, rts), r = vec - blk * rts;
-  const int x0 = blk * D * rts + r;                       // position of element 0 in the (packed) buffer
-  u64* base = buf + x0;
-  u64 v[D], o[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
-  switch (st.kind) {
-    case ST_DFTP:
-    case ST_CRTP:
-    case ST_CRTPINV: {
-      const u64* M = cst + st.mat_off;
-      static_assert(D <= 16, "16 products below 2^124 (q < 2^62) fit in 128 bits");
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        unsigned __int128 acc = 0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          if constexpr (Q32) acc += (unsigned __int128)((u64)(u32)v[c] * (u32)M[i * D + c]);
-          else acc += (unsigned __int128)v[c] * M[i * D + c];
-        }
-        // Q32: the sum is below 16 * 2^64, so its high word is below q whenever q > 16: one division step
-        if (Q32 && q > 16) o[i] = rem128((u64)(acc >> 64), (u64)acc, mc);
-        else o[i] = dot_reduce(acc, mc);
-      }
-      break;
-    }
-    case ST_L: {                         // prefix sums (l.cpp:28-57)
-      u64 s = 0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) { s = addmod(s, v[i], q); o[i] = s; }
-      break;
-    }
-    case ST_LINV: {                      // adjacent differences (l.cpp:67-98)
-      o[0] = v[0];
-#pragma unroll
-      for (int i = 1; i < D; ++i) o[i] = submod(v[i], v[i - 1], q);
-      break;
-    }
-    case ST_GPOW: {                      // g.cpp:16-35
-      const u64 last = v[D - 1];
-      o[0] = addmod(v[0], last, q);
-#pragma unroll
-      for (int i = 1; i < D; ++i) o[i] = submod(addmod(v[i], last, q), v[i - 1], q);
-      break;
-    }
-    case ST_GDEC: {                      // g.cpp:37-58
-      u64 s = v[0];
-#pragma unroll
-      for (int c = 0; c < D; ++c) s = addmod(s, v[c], q);
-      o[0] = s;
-#pragma unroll
-      for (int i = 1; i < D; ++i) o[i] = submod(v[i], v[i - 1], q);
-      break;
-    }
-    case ST_GINVPOW: {                   // g.cpp:60-90: (p-1-i) * sum_{c<=i} - (i+1) * sum_{c>i}
-      u64 tot = 0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) tot = addmod(tot, v[c], q);
-      u64 le = 0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        le = addmod(le, v[i], q);
-        const u64 re = submod(tot, le, q);
-        o[i] = submod(gmul<Q32>(smallmod((u64)(st.p - 1 - i), q), le, mc), gmul<Q32>(smallmod((u64)(i + 1), q), re, mc), q);
-      }
-      break;
-    }
-    case ST_GINVDEC: {                   // g.cpp:92-123: sum_c (c+1) v_c - p * sum_{c>i} v_c
-      u64 s = 0, tot = 0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        s = addmod(s, gmul<Q32>(smallmod((u64)(c + 1), q), v[c], mc), q);
-        tot = addmod(tot, v[c], q);
-      }
-      const u64 pm = smallmod((u64)st.p, q);
-      u64 le = 0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        le = addmod(le, v[i], q);
-        o[i] = submod(s, gmul<Q32>(pm, submod(tot, le, q), mc), q);
-      }
-      break;
-    }
-    default:
-#pragma unroll
-      for (int i = 0; i < D; ++i) o[i] = v[i];
-  }
-  if (st.tw_off >= 0) {
-    const int pi = fdiv<true>(x0, n_magic, n);
-    const int xi0 = x0 - pi * n;                          // position inside its polynomial
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const int xd = fdiv<true>(xi0 + i * rts, st.m_twdiv, st.tw_div);
-      o[i] = gmul<Q32>(o[i], cst[st.tw_off + xd - fdiv<true>(xd, st.m_twmod, st.tw_mod) * st.tw_mod], mc);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < D; ++i) base[i * rts] = o[i];
-}
-
-// every vector length the vector interpreter instantiates (p-1 and p for p = 3..13)
-__host__ __device__ constexpr bool vec_len_ok(int d) {
-  return d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 10 || d == 11 || d == 12 || d == 13;
-}
-
-template <bool Q32>
-__global__ void __launch_bounds__(512)
-k_generic_vec(i64* y, const i64* src, i64 B, int T, int n, const Stage* __restrict__ stages, int nstages,
-              const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod, int ppw, i64 ngroups) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64* buf = reinterpret_cast<u64*>(smem);
-  const i64 items = ngroups * T;
-  const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
-  for (i64 item = blockIdx.x; item < items; item += gridDim.x) {
-    const i64 g = item / T;
-    const int t = (int)(item % T);
-    const i64 b0 = g * ppw;
-    const int np = (int)((B - b0) < ppw ? (B - b0) : ppw);
-    const int tot = np * n;
-    const ModCtx mc = mod[t];
-    const u64* cst = consts + (size_t)t * cpc;
-    for (int x = threadIdx.x; x < tot; x += blockDim.x) buf[x] = canon_in(src[((size_t)b0 * n + x) * T + t], mc.q);
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-      const Stage st = stages[s];
-      if (st.kind == ST_DIAG || st.kind == ST_SCALE) {
-        for (int x = threadIdx.x; x < tot; x += blockDim.x) {
-          const int pi = fdiv<true>(x, n_magic, n);
-          buf[x] = stage_eval<true, Q32>(st, buf + pi * n, x - pi * n, cst, mc);   // element-wise: in place is safe
-        }
-      } else {
-        const int nvec = tot / st.d;
-        for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
-          switch (st.d) {
-            case 2: stage_vec<2, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 3: stage_vec<3, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 4: stage_vec<4, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 5: stage_vec<5, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 6: stage_vec<6, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 7: stage_vec<7, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 10: stage_vec<10, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 11: stage_vec<11, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 12: stage_vec<12, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            case 13: stage_vec<13, Q32>(st, buf, vec, n, n_magic, cst, mc); break;
-            default: break;   // excluded on the host (vec_len_ok)
-          }
-        }
-      }
-      __syncthreads();
-    }
-    for (int x = threadIdx.x; x < tot; x += blockDim.x) y[((size_t)b0 * n + x) * T + t] = (i64)buf[x];
-    __syncthreads();
-  }
-}
-
 hipError_t launch_generic(const GenericLaunch& a) {
   if (a.B == 0) return hipSuccess;
   const size_t lds_budget = 152 * 1024;
@@ -554,25 +387,6 @@ hipError_t launch_generic(const GenericLaunch& a) {
   u64* scratch = nullptr;
   size_t lds_bytes;
   i64 grid;
-  if (a.vec_ok && (size_t)a.n * sizeof(u64) <= 64 * 1024) {
-    // vector interpreter: one LDS buffer; pack small polynomials up to ~2048 coefficients
-    while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
-    lds_bytes = (size_t)ppw * a.n * sizeof(u64);
-    const i64 ngroups = (a.B + ppw - 1) / ppw;
-    grid = ngroups * a.T;
-    if (grid > 65536) grid = 65536;
-    // measured at m = 15015 / 1728 / 14336: 46 KiB polynomials want 512 threads (three groups per
-    // CU = 6 waves/SIMD), 1-2 K coefficient groups 128
-    const size_t coeffs = (size_t)ppw * a.n;
-    const int vthreads = coeffs >= 4096 ? 512 : (coeffs >= 2048 ? 256 : 128);
-    if (a.q32)
-      hipLaunchKernelGGL((k_generic_vec<true>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y,
-                         a.src ? a.src : a.y, a.B, a.T, (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
-    else
-      hipLaunchKernelGGL((k_generic_vec<false>), dim3((unsigned)grid), dim3(vthreads), lds_bytes, a.stream, a.y,
-                         a.src ? a.src : a.y, a.B, a.T, (int)a.n, a.stages, a.nstages, a.consts, a.cpc, a.mod, ppw, ngroups);
-    return hipGetLastError();
-  }
   if (per_poly <= lds_budget) {
     // pack small polynomials: aim for >= 2048 coefficients per workgroup, <= 32 KiB per buffer
     while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;

@@ -386,6 +386,13 @@ int plan_upload(Plan& P) {
   // polynomials too large for the LDS ping-pong run the generic path out of an HBM scratch ring
   // (allocated per call, stream-ordered: run_prog in capi.cpp)
   P.needs_scratch = 2 * (size_t)P.n * sizeof(u64) > 152 * 1024;
+  // class of the vector interpreter: 32-bit residues when every q < 2^32; a dot product of up to 13
+  // terms in ONE 64-bit accumulator when 13 (q-1)^2 < 2^64
+  P.mixed_cls = 2;
+  for (u64 q : P.qs) {
+    if ((unsigned __int128)13 * (q - 1) * (q - 1) >= ((unsigned __int128)1 << 64)) P.mixed_cls = P.mixed_cls < 1 ? P.mixed_cls : 1;
+    if (q >= ((u64)1 << 32)) P.mixed_cls = 0;
+  }
   HIPCK(hipGetDevice(&P.device_id));
   P.device = true;
   return LOLHIP_OK;

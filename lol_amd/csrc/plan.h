@@ -95,6 +95,7 @@ struct Plan {
   Pow2Tables pow2;
   bool is_pow2 = false;
   int device_id = -1;                       // HIP device the tables were uploaded to
+  int mixed_cls = 0;                        // arithmetic/storage class of the vector interpreter (mixed.hip)
   // Nothing in a plan is written after plan_upload(): per-call workspaces (the operand copy of the
   // unfused poly-mul, the HBM ping-pong ring of polynomials too large for LDS) are stream-ordered
   // allocations made by the call that needs them, so host threads and streams can share a plan.

@@ -1,5 +1,5 @@
 // tools/bench_kernels.cpp — torch-free timing driver over the C ABI (development aid for
-// rocprofv3 runs).  usage: bench_kernels <log2 m> <T> <B> <op: crt|crtinv|polymul|roundtrip> <iters> [qbits]
+// rocprofv3 runs).  usage: bench_kernels <log2 m | mNNN (any index, e.g. m15015)> <T> <B> <op: crt|crtinv|polymul|roundtrip|l|mulgpow|divgdec> <iters> [qbits]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,17 +10,22 @@
 #include <dlfcn.h>
 #define CK(x) do{ if((x)!=hipSuccess){ printf("hip error line %d\n", __LINE__); return 1; } }while(0)
 int main(int argc, char** argv){
-  int lm = argc>1? atoi(argv[1]) : 14; int T = argc>2? atoi(argv[2]) : 1; long B = argc>3? atol(argv[3]) : 4096;
+  int lm = (argc>1 && argv[1][0] != 'm') ? atoi(argv[1]) : 14; long marb = (argc>1 && argv[1][0] == 'm') ? atol(argv[1] + 1) : 0;
+  int T = argc>2? atoi(argv[2]) : 1; long B = argc>3? atol(argv[3]) : 4096;
   const char* op = argc>4? argv[4] : "polymul"; int iters = argc>5? atoi(argv[5]) : 10; int qbits = argc>6? atoi(argv[6]) : 60;
-  lolhip_pp pp{2,(int16_t)lm}; std::vector<int64_t> qs; int64_t lower = (int64_t)1<<qbits;
-  for(int t=0;t<T;t++){ int64_t q = lolhip_good_q((int64_t)1<<lm, lower); qs.push_back(q); lower = q; }
-  lolhip_plan* P; int rc = lolhip_plan_create(&pp,1,qs.data(),T,0,&P); if(rc){ printf("plan rc=%d\n",rc); return 1; }
+  std::vector<lolhip_pp> pps; long mval = marb ? marb : ((long)1 << lm);
+  if (!marb) pps.push_back(lolhip_pp{2,(int16_t)lm});
+  else { long r = marb; for (long p = 2; r > 1; ++p) { int e = 0; while (r % p == 0) { r /= p; ++e; } if (e) pps.push_back(lolhip_pp{(int16_t)p,(int16_t)e}); } }
+  std::vector<int64_t> qs; int64_t lower = (int64_t)1<<qbits;
+  for(int t=0;t<T;t++){ int64_t q = lolhip_good_q(mval, lower); qs.push_back(q); lower = q; }
+  lolhip_plan* P; int rc = lolhip_plan_create(pps.data(),(int)pps.size(),qs.data(),T,0,&P); if(rc){ printf("plan rc=%d\n",rc); return 1; }
   long n = lolhip_plan_n(P); size_t cnt = (size_t)B*n*T;
   std::vector<int64_t> h(cnt); std::mt19937_64 rng(5); for(size_t i=0;i<cnt;i++) h[i] = (int64_t)(rng() % (uint64_t)qs[i%T]);
   int64_t *a,*b,*c; CK(hipMalloc(&a,cnt*8)); CK(hipMalloc(&b,cnt*8)); CK(hipMalloc(&c,cnt*8));
   CK(hipMemcpy(a,h.data(),cnt*8,hipMemcpyHostToDevice)); CK(hipMemcpy(b,h.data(),cnt*8,hipMemcpyHostToDevice));
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run=[&]()->int{ if(!strcmp(op,"crt")) return lolhip_crt_batch(P,0,a,B); if(!strcmp(op,"crtinv")) return lolhip_crtinv_batch(P,0,a,B);
+    if(!strcmp(op,"l")) return lolhip_l_batch(P,0,a,B); if(!strcmp(op,"mulgpow")) return lolhip_mulgpow_batch(P,0,a,B); if(!strcmp(op,"divgdec")) return lolhip_divgdec_batch(P,0,a,B);
     if(!strcmp(op,"roundtrip")){ int r=lolhip_crt_batch(P,0,a,B); return r? r: lolhip_crtinv_batch(P,0,a,B);} return lolhip_polymul_batch(P,0,c,a,b,B); };
   unsigned long long* dst = nullptr; size_t nw = (size_t)B*T*64; 
   typedef int (*setfn)(unsigned long long*); setfn sf = (setfn)dlsym(RTLD_DEFAULT, "lolhip_debug_set_stamps");
@@ -34,6 +39,6 @@ int main(int argc, char** argv){
     for(size_t w=0;w<nwv;w++){ int prev=-1; for(int i=0;i<32;i++){ if(hs[w*32+i]==0) continue; if(prev>=0){ sum[i]+= (double)(hs[w*32+i]-hs[w*32+prev]); cnt[i]++; } prev=i; } }
     if(getenv("LOLHIP_STAMP_DUMP")){ FILE* f=fopen(getenv("LOLHIP_STAMP_DUMP"),"wb"); fwrite(hs.data(),8,hs.size(),f); fclose(f); }
     for(int i=0;i<32;i++) if(cnt[i]) printf("  stamp %2d: +%8.0f cycles (avg over %ld waves)\n", i, sum[i]/cnt[i], cnt[i]); (void)last; }
-  printf("%s m=2^%d n=%ld T=%d B=%ld q~2^%d: %.4f ms/iter  %.3f M items/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", op, lm, n, T, B, qbits, ms, B/ms/1e3, bytes/ms/1e6, bytes/ms/1e6/80.0);
+  printf("%s m=%ld n=%ld T=%d B=%ld q~2^%d: %.4f ms/iter  %.3f M items/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", op, mval, n, T, B, qbits, ms, B/ms/1e3, bytes/ms/1e6, bytes/ms/1e6/80.0);
   return 0;
 }
