@@ -14,6 +14,15 @@ so scaling is weak: each rank multiplies its own 4096-polynomial shard.
 Prints ONE JSON line (rank 0).  `roofline.achieved` is algorithmic bytes
 (3 * n * T * 8 per poly-mul) over the mean launch duration measured with
 HIP events on the launch stream inside the timed region (one pair around the K launches).
+
+Before the W warm-up steps the same step runs untimed for ~0.4 s, so that a short timed
+region (the driver's --steps 20 is 12 ms) sees the clocks the chip holds under this load and
+not its ramp.  After the timed region, N = 1 only and outside the metric, `secondary` carries
+the rest of SURVEY.md 8(d)'s table — each leg {ms, items_per_s, alg_GBps, frac of 8 TB/s}: the
+same launch in the other arithmetic classes, config 3's ciphertext product, config 4 at both
+moduli, config 5's key switch and ring embedding, and the drop-in (host-pointer) symbols at
+config 1 beside lol-cpp on one host core.  For N > 1 a `gather` object times the one optional
+collective (all-gather of the result shards) and gives poly-muls/s with it included.
 """
 from __future__ import annotations
 
@@ -96,37 +105,182 @@ def cpu_baseline(q: int, budget_s: float = 12.0):
     }
 
 
+def _leg(ms, items, alg_bytes, **extra):
+    d = {"ms": round(ms, 4), "items_per_s": round(items / ms * 1e3, 1), "alg_GBps": round(alg_bytes / ms / 1e6, 1),
+         "frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    d.update(extra)
+    return d
+
+
+def _good_qs(lol_amd, m, lower, T):
+    out, lo = [], lower
+    for _ in range(T):
+        lo = lol_amd.good_q(m, lo)
+        out.append(lo)
+    return out
+
+
 def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
-    """Not the metric: the same launch shape in the other regimes, for context (N = 1 only).
-    ms per launch from HIP events; GB/s = algorithmic bytes / time."""
-    def timed(fn, iters=10):
-        fn()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for s_, e_ in ev:
-            s_.record(stream); fn(); e_.record(stream)
+    """Not the metric: the rest of SURVEY.md 8(d)'s table (N = 1 only).  ms per launch from HIP
+    events on the launch stream; alg_GBps = compulsory bytes of the fused ideal / time."""
+    st = stream.cuda_stream
+
+    def timed(fn, iters=10, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
         torch.cuda.synchronize()
-        return sum(s_.elapsed_time(e_) for s_, e_ in ev) / iters
+        return e0.elapsed_time(e1) / iters
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+
+    def rnd(qs, *shape):
+        return torch.stack([torch.randint(0, q, shape, dtype=torch.int64, device="cuda", generator=gen) for q in qs], dim=-1)
+
     slab = B * n * T * 8
     out = {}
+    # ---- config 2's launch shape in the other arithmetic classes -----------------------------
     c.copy_(a)
-    ms = timed(lambda: plan.crt(c, stream=stream.cuda_stream))
-    out["crt_61bit"] = {"ms": round(ms, 4), "GBps": round(2 * slab / ms / 1e6, 1)}
-    q30 = lol_amd.good_q(M_INDEX, 1 << 29)
-    p30 = lol_amd.Plan([(2, 14)], [q30])
-    x = a % q30
-    y = torch.empty_like(x)
-    x2 = (a + 1) % q30
-    ms = timed(lambda: p30.polymul(x, x2, out=y, stream=stream.cuda_stream))
-    out["polymul_30bit"] = {"ms": round(ms, 4), "poly_muls_per_s": round(B / ms * 1e3, 1), "GBps": round(3 * slab / ms / 1e6, 1), "q": q30}
-    y.copy_(x)
-    ms = timed(lambda: p30.crt(y, stream=stream.cuda_stream))
-    out["crt_30bit"] = {"ms": round(ms, 4), "GBps": round(2 * slab / ms / 1e6, 1)}
-    q31 = 1073872897            # config 2's CT-valid modulus (SURVEY.md 8d): just above 2^30
-    p31 = lol_amd.Plan([(2, 14)], [q31])
-    x, x2 = a % q31, (a + 1) % q31
-    ms = timed(lambda: p31.polymul(x, x2, out=y, stream=stream.cuda_stream))
-    out["polymul_31bit"] = {"ms": round(ms, 4), "poly_muls_per_s": round(B / ms * 1e3, 1), "GBps": round(3 * slab / ms / 1e6, 1), "q": q31}
+    out["crt_61bit"] = _leg(timed(lambda: plan.crt(c, stream=st)), B, 2 * slab)
+    y = torch.empty_like(a)
+    for name, q_ in (("30bit", lol_amd.good_q(M_INDEX, 1 << 29)), ("31bit", 1073872897)):   # 31bit: config 2's CT-valid modulus
+        pq = lol_amd.Plan([(2, 14)], [q_])
+        x, x2 = a % q_, (a + 1) % q_
+        out[f"polymul_{name}"] = _leg(timed(lambda: pq.polymul(x, x2, out=y, stream=st)), B, 3 * slab, q=q_)
+        y.copy_(x)
+        out[f"crt_{name}"] = _leg(timed(lambda: pq.crt(y, stream=st)), B, 2 * slab, q=q_)
+        del pq, x, x2
+    del y
+    L = lol_amd.lib()
+    ptr = lambda t_: t_.data_ptr()
+    # ---- config 3: m = 2^15, four ~59-bit moduli, ciphertext x ciphertext (SymmSHE.hs:444-449) ----
+    qs3 = _good_qs(lol_amd, 1 << 15, 1 << 59, 4)
+    P3 = lol_amd.Plan([(2, 15)], qs3)
+    B3 = 256
+    ops = [rnd(qs3, B3, P3.n) for _ in range(4)]
+    outs = [torch.empty_like(ops[0]) for _ in range(3)]
+    slab3 = B3 * P3.n * P3.T * 8
+    ms = timed(lambda: L.lolhip_ctmul_crt_batch(P3._h, st, *map(ptr, ops + outs), B3))
+    out["c3_ctmul_crt"] = _leg(ms, B3, 7 * slab3, workload="m=2^15 T=4 59-bit B=256: (g c0 d0, g(c0 d1 + c1 d0), g c1 d1), CRT basis in and out")
+
+    def ring_product():           # powerful basis in and out: 4 crt, the fused product, 3 crtInv
+        for o in ops:
+            P3.crt(o, stream=st)
+        L.lolhip_ctmul_crt_batch(P3._h, st, *map(ptr, ops + outs), B3)
+        for o in outs:
+            P3.crtInv(o, stream=st)
+    ms = timed(ring_product, iters=5, warm=1)
+    out["c3_ctmul_pow"] = _leg(ms, B3, 7 * slab3, workload="the same from and to the powerful basis: 4 crt + product + 3 crtInv (8 launches)")
+    del ops, outs, P3
+    # ---- config 4: m = 15015, batch 1024, q just above 2^30 and just above 2^60 ---------------
+    pps4 = lol_amd.factor_pps(15015)
+    for name, lower in (("q30", 1 << 30), ("q60", 1 << 60)):
+        q4 = lol_amd.good_q(15015, lower)
+        P4 = lol_amd.Plan(pps4, [q4])
+        B4 = 1024
+        x, x2 = rnd([q4], B4, P4.n), rnd([q4], B4, P4.n)
+        y = torch.empty_like(x)
+        slab4 = B4 * P4.n * 8
+        out[f"c4_polymul_{name}"] = _leg(timed(lambda: P4.polymul(x, x2, out=y, stream=st)), B4, 3 * slab4, q=q4)
+        out[f"c4_crt_{name}"] = _leg(timed(lambda: P4.crt(x, stream=st)), B4, 2 * slab4, q=q4)
+        del P4, x, x2, y
+    # ---- config 5: key switch at m' = 2048, q = (1017857, 1032193); ring embedding 2048 -> 14336 ----
+    qs5 = [1017857, 1032193]
+    P5 = lol_amd.Plan([(2, 11)], qs5)
+    B5 = 8192                                  # one GPU's shard of the 65536-ciphertext batch
+    slab5 = B5 * P5.n * P5.T * 8
+    c2 = rnd(qs5, B5, P5.n)
+    add = torch.stack([rnd(qs5, B5, P5.n) for _ in range(2)])
+    res = torch.empty_like(add)
+    for name, base in (("trivgad", 0), ("base256", 256)):
+        Ld = P5.decomposeLen(base)
+        hint = rnd(qs5, Ld, 2, P5.n)
+        work = torch.empty((Ld, B5, P5.n, P5.T), dtype=torch.int64, device="cuda")
+        ms = timed(lambda: L.lolhip_keyswitch_batch(P5._h, st, ptr(c2), base, ptr(hint), 2, ptr(add), ptr(res), ptr(work), B5))
+        out[f"c5_keyswitch_{name}"] = _leg(ms, B5, 5 * slab5, digits=Ld, workload="keySwitchQuadCirc body: c2 in, 2 addends in, 2 out (SymmSHE.hs:361-371), m'=2048 T=2 B=8192")
+        del hint, work
+    del c2, add, res
+    P5h = lol_amd.Plan(lol_amd.factor_pps(2048 * 7), qs5)
+    X = lol_amd.Ext(P5, P5h)
+    lo = rnd(qs5, B5, P5.n)
+    hi = torch.empty((B5, P5h.n, 2), dtype=torch.int64, device="cuda")
+    ms = timed(lambda: X.embedCRT(lo, out=hi, stream=st))
+    out["c5_embed_crt"] = _leg(ms, B5, (P5.n + P5h.n) * 2 * 8 * B5, workload="embedCRT 2048 -> 14336 (Extension.hs:81-85), T=2 B=8192")
+    del X, lo, hi, P5h, P5
     return out
+
+
+def dropin_c1():
+    """Config 1 through the drop-in symbols (host pointers, one polynomial per call, the path the
+    unchanged CT shim takes: Backend.hs:304-337) beside lol-cpp itself on one host core."""
+    import ctypes as C
+
+    import numpy as np
+
+    import lol_amd
+    from oracle import lolmath as lm
+    from oracle.oracle import CTREF_SO, CpuRef, Params
+
+    m, q = 1024, 12289
+    P = Params([(2, 10)], [q])
+
+    class PP(C.Structure):
+        _fields_ = [("prime", C.c_int16), ("exponent", C.c_int16)]
+    pe = (PP * 1)()
+    pe[0].prime, pe[0].exponent = 2, 10
+    qa = np.array([q], dtype=np.int64)
+    ru = [np.array(t, dtype=np.int64) for t in P.ru]
+    rui = [np.array(t, dtype=np.int64) for t in P.ruinv]
+    rup = (C.c_void_p * 1)(ru[0].ctypes.data)
+    ruip = (C.c_void_p * 1)(rui[0].ctypes.data)
+    mh = np.array(P.mhatinv, dtype=np.int64)
+    rng = np.random.default_rng(1)
+    a0, b0 = P.random(rng, 1)[0], P.random(rng, 1)[0]
+    want = CpuRef().polymul(P, a0[None], b0[None]).reshape(P.n, 1)
+
+    def per_call(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def measure(path, totm_type):
+        """The SAME ctypes calls against either library: the symbols are drop-in identical
+        (lol-cpp declares totm as int32 hDim_t, types.h:22; Haskell and liblolhip pass int64)."""
+        Lh = C.CDLL(path)
+        i16, vp = C.c_int16, C.c_void_p
+        Lh.tensorCRTRq.argtypes = [i16, vp, totm_type, vp, i16, vp, vp]
+        Lh.tensorCRTInvRq.argtypes = [i16, vp, totm_type, vp, i16, vp, vp, vp]
+        Lh.mulRq.argtypes = [i16, vp, vp, totm_type, vp]
+        for nm in ("tensorCRTRq", "tensorCRTInvRq", "mulRq"):
+            getattr(Lh, nm).restype = None
+
+        def crt(y):
+            Lh.tensorCRTRq(1, y.ctypes.data, P.n, pe, 1, rup, qa.ctypes.data)
+
+        def polymul():
+            a, b = a0.copy(), b0.copy()
+            crt(a); crt(b)
+            Lh.mulRq(1, a.ctypes.data, b.ctypes.data, P.n, qa.ctypes.data)
+            Lh.tensorCRTInvRq(1, a.ctypes.data, P.n, pe, 1, ruip, mh.ctypes.data, qa.ctypes.data)
+            return a
+        ok = bool(np.array_equal(polymul(), want))
+        y = a0.copy()
+        return round(per_call(lambda: crt(y), 300), 1), round(per_call(polymul, 100), 1), ok
+
+    g_crt, g_pm, g_ok = measure(lol_amd.lib_path(), C.c_int64)
+    res = {"workload": "m=1024 n=512 q=12289, one polynomial per call through the drop-in symbols (host pointers; BASELINE.json configs[0])",
+           "gpu_us_per_tensorCRTRq": g_crt, "gpu_us_per_polymul": g_pm, "parity_ok": g_ok}
+    if os.path.exists(CTREF_SO):
+        c_crt, c_pm, c_ok = measure(CTREF_SO, C.c_int32)
+        res.update({"lolcpp_us_per_tensorCRTRq_one_core": c_crt, "lolcpp_us_per_polymul_one_core": c_pm, "lolcpp_parity_ok": c_ok})
+    return res
 
 
 def main():
@@ -136,6 +290,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--clock-warmup-s", type=float, default=0.4)
     args = ap.parse_args()
 
     import numpy as np
@@ -170,6 +326,12 @@ def main():
     def step():
         plan.polymul(a, b, out=c, stream=stream.cuda_stream)
 
+    # clock warm-up (untimed, not counted in --warmup): the chip's clocks settle under THIS load
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.clock_warmup_s:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     # one HIP-event pair on the launch stream around the K launches (they queue back to back;
@@ -192,6 +354,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)
+
+    # ---- N > 1: the one optional collective, all-gather of the result shards ----
+    gather = None
+    if dist is not None:
+        from lol_amd.dist import allgather_batch
+        full = allgather_batch(c, B * world)             # warm (RCCL channel setup)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            full = allgather_batch(c, B * world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = torch.tensor([(time.perf_counter() - tg0) / reps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather = float(tg.item())
+        del full
 
     # ---- correctness of what was timed: strided sample against the CPU oracle -----
     parity = None
@@ -233,12 +413,23 @@ def main():
                        "sharding": f"batch x{n_gpus}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_pow2<13,2> (fused crt,crt,mul,crtInv)", "kernel_ms": round(kern_ms, 4),
+                         "traffic_source": "stored: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel, separate passes); not measured by this run",
+                         "kernel": "k_pow2<13,2,1> (fused crt,crt,mul,crtInv)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_sample_ok": parity,
+            "parity_note": ("bit-exact vs the pinned CPU restatement (oracle/cpu_ref.c, itself pinned on lol-cpp's golden vectors); "
+                            "lol-cpp's own Zq overflows at this 61-bit modulus (types.h:79-84) - the figure at a modulus "
+                            "where CT is literally checkable is secondary.polymul_31bit"),
         }
-        if n_gpus == 1:
+        if gather is not None:
+            shard_bytes = B * n * T * 8
+            out["gather"] = {"ms": round(gather * 1e3, 4), "shard_bytes": shard_bytes,
+                             "GBps_per_rank_received": round((world - 1) * shard_bytes / gather / 1e9, 1),
+                             "poly_muls_per_s_with_gather": round(n_gpus * B / (elapsed / args.steps + gather), 1),
+                             "note": "all-gather of every rank's result shard after one step (lol_amd.dist.allgather_batch, RCCL); optional: results consumed where produced need no collective"}
+        if n_gpus == 1 and not args.no_secondary:
             out["secondary"] = secondary(lol_amd, torch, plan, a, c, B, n, T, stream)
+            out["secondary"]["dropin_c1"] = dropin_c1()
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(q)
         print(json.dumps(out, ensure_ascii=False), flush=True)

@@ -137,6 +137,20 @@ LOLHIP_API int lolhip_divgdec_batch(const lolhip_plan *p, void *stream, int64_t 
 LOLHIP_API int lolhip_mulgcrt_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
 LOLHIP_API int lolhip_divgcrt_batch(const lolhip_plan *p, void *stream, int64_t *y, int64_t B);
 
+/* --- floating-point members of the class, float64, tolerance contract:
+ *     relative 1e-12 against lol-cpp on the same inputs (integer paths are bit-exact) --------
+ * crtc / crtinvc: replace tensorCRTC / tensorCRTInvC (crt.cpp:583-598), the CRT over C with
+ *   omega_m = exp(2 pi i / m) that UCyc uses when a modulus has no CRT basis (CRTExt,
+ *   UCyc.hs:422-444).  y [B][n] complex doubles, (re, im) interleaved, in place; crtinvc includes
+ *   the mhat^-1 scaling.  Works for any plan (the moduli play no role).
+ * gaussian_dec: replaces tensorGaussianDec (random.cpp:19-64; caller CPP.hs:376-389): y [B][n]
+ *   doubles, on entry iid real Gaussians, on exit the sample in the decoding basis (the caller
+ *   draws and scales the Gaussians and rounds the result, as cDispatchGaussian does).
+ * Both need n <= 8192 and every prime of m <= 13, else LOLHIP_ERR_INVALID. */
+LOLHIP_API int lolhip_crtc_batch        (const lolhip_plan *p, void *stream, double *y, int64_t B);
+LOLHIP_API int lolhip_crtinvc_batch     (const lolhip_plan *p, void *stream, double *y, int64_t B);
+LOLHIP_API int lolhip_gaussian_dec_batch(const lolhip_plan *p, void *stream, double *y, int64_t B);
+
 /* --- ring extension m | m' (twace/embed, Extension.hs:54-129) ------------------- */
 LOLHIP_API int lolhip_ext_create(const lolhip_plan *p_m, const lolhip_plan *p_mprime, lolhip_ext **out);
 LOLHIP_API void lolhip_ext_destroy(lolhip_ext *x);

@@ -301,6 +301,34 @@ int lolhip_divgcrt_batch(const lolhip_plan* p, void* stream, int64_t* y, int64_t
              ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
+// ---- floating-point members of the class ---------------------------------
+
+static int float_ready(const lolhip_plan* p) {
+  int rc = need_device(p); if (rc) return rc;
+  return p->P.float_ok ? LOLHIP_OK : LOLHIP_ERR_INVALID;      // n > 8192 or a prime > 13
+}
+int lolhip_crtc_batch(const lolhip_plan* p, void* stream, double* y, int64_t B) {
+  int rc = float_ready(p); if (rc) return rc;
+  if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
+  const Plan& P = p->P;
+  return launch_cplx((hipStream_t)stream, y, B, P.n, P.prog_crt.d_stages, P.prog_crt.nstages, P.d_cconsts) == hipSuccess
+             ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+int lolhip_crtinvc_batch(const lolhip_plan* p, void* stream, double* y, int64_t B) {
+  int rc = float_ready(p); if (rc) return rc;
+  if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
+  const Plan& P = p->P;
+  return launch_cplx((hipStream_t)stream, y, B, P.n, P.prog_crtinv.d_stages, P.prog_crtinv.nstages, P.d_cconsts) == hipSuccess
+             ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+int lolhip_gaussian_dec_batch(const lolhip_plan* p, void* stream, double* y, int64_t B) {
+  int rc = float_ready(p); if (rc) return rc;
+  if (B < 0 || (B > 0 && !y)) return LOLHIP_ERR_INVALID;
+  const Plan& P = p->P;
+  return launch_gauss((hipStream_t)stream, y, B, P.n, P.prog_gauss.d_stages, P.prog_gauss.nstages, P.d_rconsts) == hipSuccess
+             ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+
 // ---- ring-level pipelines ---------------------------------------------
 
 namespace {

@@ -78,6 +78,10 @@ struct MixedLaunch {
 bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T);
 hipError_t launch_mixed(const MixedLaunch& a);
 
+// floating-point side (floatpath.hip): y [B][n] complex doubles (re, im interleaved) / doubles, in place
+hipError_t launch_cplx(hipStream_t s, double* y, i64 B, i64 n, const Stage* stages, int nstages, const double* cconsts);
+hipError_t launch_gauss(hipStream_t s, double* y, i64 B, i64 n, const Stage* stages, int nstages, const double* rconsts);
+
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod);
 hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,
                          int T, const ModCtx* mod);

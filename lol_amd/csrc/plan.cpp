@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
+#include <complex>
 #include <cstring>
 
 #include "lolhip.h"
@@ -12,17 +14,49 @@ namespace lolhip {
 
 namespace {
 
-struct PoolBuilder {
+template <typename E>
+struct PoolBuilderT {
   int T;
-  std::vector<std::vector<u64>> pool;   // [t][...]
-  explicit PoolBuilder(int T_) : T(T_), pool((size_t)T_) {}
+  std::vector<std::vector<E>> pool;   // [t][...]
+  explicit PoolBuilderT(int T_) : T(T_), pool((size_t)T_) {}
   int size() const { return (int)pool[0].size(); }
   // append one table per component; tab[t] all of equal length; returns offset
-  int add(const std::vector<std::vector<u64>>& tab) {
+  int add(const std::vector<std::vector<E>>& tab) {
     int off = size();
     for (int t = 0; t < T; ++t) pool[(size_t)t].insert(pool[(size_t)t].end(), tab[(size_t)t].begin(), tab[(size_t)t].end());
     return off;
   }
+  template <typename Fn> int per_comp(Fn fn, size_t len) {
+    std::vector<std::vector<E>> tab((size_t)T, std::vector<E>(len));
+    for (int t = 0; t < T; ++t) fn(t, tab[(size_t)t]);
+    return add(tab);
+  }
+};
+typedef PoolBuilderT<u64> PoolBuilder;
+
+// The element rings the CRT stage program is instantiated over.  Both give, for prime power k,
+// component t and direction, the table ru[i] = omega_{pp_k}^{+-i} (CPP.hs:422-442).
+struct ModRing {            // Z_q, per RNS component
+  typedef u64 E;
+  const Plan& P; const std::vector<u64>& qs; bool ok;     // ok = the plan has a CRT basis (otherwise the tables are zeros)
+  int T() const { return (int)qs.size(); }
+  E ru(int k, bool inv, int t, i64 i) const { return ok ? (u64)(inv ? P.ruinv : P.ru)[(size_t)k][(size_t)(i * T() + t)] : 0; }
+  E one(int t) const { return 1 % qs[(size_t)t]; }
+  E sub(int t, E a, E b) const { const u64 q = qs[(size_t)t]; return (a + q - b) % q; }
+  E mhatinv(int t) const { return (u64)P.mhatinv[(size_t)t]; }
+};
+struct CplxRing {           // C with omega_m = exp(2 pi i / m) (what Lol's Complex instance of CRTrans uses)
+  typedef std::complex<double> E;
+  const std::vector<PP>& pps; i64 m;
+  int T() const { return 1; }
+  E ru(int k, bool inv, int, i64 i) const {
+    const i64 pp = ipow(pps[(size_t)k].p, pps[(size_t)k].e);
+    const double ang = 2.0 * M_PI * (double)(i % pp) / (double)pp;
+    return E(std::cos(ang), inv ? -std::sin(ang) : std::sin(ang));
+  }
+  E one(int) const { return E(1.0, 0.0); }
+  E sub(int, E a, E b) const { return a - b; }
+  E mhatinv(int) const { return E(1.0 / (double)value_hat(m), 0.0); }
 };
 
 struct ProgBuilder {
@@ -78,6 +112,90 @@ static bool valid_pps(const std::vector<PP>& pps) {
     last = pe.p;
   }
   return true;
+}
+
+// The CRT / CRT^-1 stage programs of index m = prod pps over ring R, constants appended to `pool`
+// (tensor.h:76-95 over crt.cpp:459-560).  The Stage lists depend on pps only; called once per
+// ring with pools that share a prefix, the offsets agree, so ONE stage list serves Z_q and C.
+template <typename Ring>
+static void build_crt_programs(const std::vector<PP>& pps, const Ring& R, PoolBuilderT<typename Ring::E>& pool,
+                               ProgBuilder* crt, ProgBuilder* crtinv, ProgBuilder* crt_odd, ProgBuilder* crtinv_odd) {
+  typedef typename Ring::E E;
+  const int K = (int)pps.size();
+  i64 rts = 1;
+  for (int k = 0; k < K; ++k) {
+    const int p = pps[(size_t)k].p, e = pps[(size_t)k].e;
+    const i64 mprime = ipow(p, e - 1), phi = (p - 1) * mprime;
+    for (int inv = 0; inv < 2; ++inv) {
+      DualBuilder pb{inv ? crtinv : crt, (k >= 1) ? (inv ? crtinv_odd : crt_odd) : nullptr};
+      auto ru = [&](int t, i64 i) { return R.ru(k, inv != 0, t, i); };
+      // omega_p^j, j < p  (ru[j * p^(e-1)], crt.cpp:526 rustride = mprime)
+      const int wp_off = pool.per_comp([&](int t, std::vector<E>& o) {
+        for (int j = 0; j < p; ++j) o[(size_t)j] = ru(t, j * mprime);
+      }, (size_t)p);
+      // dense coefficient matrices, so the kernel does no index arithmetic per term:
+      //   DFT_p[i][c] = w^(c*i)               (crt.cpp:226-245)
+      //   CRT_p[i][c] = w^(c*(i+1))           (crt.cpp:324-345)
+      //   CRT_p^-1[i][c] = w^(i*(c+1)) - w^(p-c-1)   (crt.cpp:433-456, the shift folded in)
+      auto wpow = [&](int t, i64 ex) { return ru(t, (ex % p) * mprime); };
+      const int mat_dft = pool.per_comp([&](int t, std::vector<E>& o) {
+        for (int i = 0; i < p; ++i) for (int c = 0; c < p; ++c) o[(size_t)(i * p + c)] = wpow(t, (i64)c * i);
+      }, (size_t)p * p);
+      const int mat_crt = (p == 2) ? -1 : pool.per_comp([&](int t, std::vector<E>& o) {
+        for (int i = 0; i < p - 1; ++i) for (int c = 0; c < p - 1; ++c)
+          o[(size_t)(i * (p - 1) + c)] = inv ? R.sub(t, wpow(t, (i64)i * (c + 1)), wpow(t, p - c - 1)) : wpow(t, (i64)c * (i + 1));
+      }, (size_t)(p - 1) * (p - 1));
+      // crtTwiddle diagonal over the phi(pp) digit (crt.cpp:35-81)
+      int ctw_off = -1;
+      if (mprime > 1)
+        ctw_off = pool.per_comp([&](int t, std::vector<E>& o) {
+          for (i64 i0 = 0; i0 < mprime; ++i0)
+            for (int i1 = 0; i1 < p - 1; ++i1)
+              o[(size_t)(i0 * (p - 1) + i1)] = ru(t, digit_rev(p, e - 1, i0) * (i1 + 1));
+        }, (size_t)phi);
+      // dftTwiddle diagonals, one per DFT stage of DFT_{p^(e-1)} (crt.cpp:84-126, 459-516)
+      const int e1 = e - 1;
+      const i64 rts1 = rts * (p - 1);
+      auto dft_diag = [&](int ecur, i64 dim, i64 twidRuStride) -> int {
+        if (dim / p <= 1) return -1;
+        return pool.per_comp([&](int t, std::vector<E>& o) {
+          for (i64 c = 0; c < dim; ++c) {
+            i64 i0 = c / p, i1 = c % p;
+            o[(size_t)c] = (i0 == 0 || i1 == 0) ? R.one(t) : ru(t, digit_rev(p, ecur - 1, i0) * i1 * twidRuStride);
+          }
+        }, (size_t)dim);
+      };
+      if (!inv) {
+        if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off, mat_crt);
+        if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
+        i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
+        int ecur = e1;
+        for (int i = 0; i < e1; ++i) {
+          const i64 rtsDim = rts1 * rtsScale;
+          pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
+          int off = dft_diag(ecur, ltsScale * p, twidRuStride);
+          if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
+          ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
+        }
+      } else {
+        i64 ltsScale = 1, rtsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, twidRuStride = e1 > 0 ? p * ipow(p, e1 - 1) : 0;
+        int ecur = 1;
+        for (int i = 0; i < e1; ++i) {
+          const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
+          int off = dft_diag(ecur, ltsScaleP, twidRuStride);
+          if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
+          pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
+          ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
+        }
+        if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
+        if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off, mat_crt);
+      }
+    }
+    rts *= phi;
+  }
+  // mhat^-1 (crt.cpp:573-579)
+  const int mh_off = pool.per_comp([&](int t, std::vector<E>& o) { o[0] = R.mhatinv(t); }, 1);
+  crtinv->diag(mh_off, 1, 1);
 }
 
 int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>& qs,
@@ -185,85 +303,9 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
 
   ProgBuilder crt, crtinv, crt_odd, crtinv_odd;
   const bool split2 = K >= 2 && pps[0].p == 2;   // odd-only programs skip the first (2-power) factor
-  if (P.has_crt) {
-    i64 rts = 1;
-    for (int k = 0; k < K; ++k) {
-      const int p = pps[(size_t)k].p, e = pps[(size_t)k].e;
-      const i64 mprime = ipow(p, e - 1), phi = (p - 1) * mprime;
-      for (int inv = 0; inv < 2; ++inv) {
-        const std::vector<i64>& rutab = inv ? P.ruinv[(size_t)k] : P.ru[(size_t)k];
-        DualBuilder pb{inv ? &crtinv : &crt, (split2 && k >= 1) ? (inv ? &crtinv_odd : &crt_odd) : nullptr};
-        // omega_p^j, j < p  (ru[j * p^(e-1)], crt.cpp:526 rustride = mprime)
-        const int wp_off = per_comp([&](int t, std::vector<u64>& o) {
-          RuView r{rutab, T, t};
-          for (int j = 0; j < p; ++j) o[(size_t)j] = r(j * mprime);
-        }, (size_t)p);
-        // dense coefficient matrices, so the kernel does no index arithmetic per term:
-        //   DFT_p[i][c] = w^(c*i)               (crt.cpp:226-245)
-        //   CRT_p[i][c] = w^(c*(i+1))           (crt.cpp:324-345)
-        //   CRT_p^-1[i][c] = w^(i*(c+1)) - w^(p-c-1)   (crt.cpp:433-456, the shift folded in)
-        auto wpow = [&](int t, i64 ex) { RuView r{rutab, T, t}; return r((ex % p) * mprime); };
-        const int mat_dft = per_comp([&](int t, std::vector<u64>& o) {
-          for (int i = 0; i < p; ++i) for (int c = 0; c < p; ++c) o[(size_t)(i * p + c)] = wpow(t, (i64)c * i);
-        }, (size_t)p * p);
-        const int mat_crt = (p == 2) ? -1 : per_comp([&](int t, std::vector<u64>& o) {
-          const u64 q = qs[(size_t)t];
-          for (int i = 0; i < p - 1; ++i) for (int c = 0; c < p - 1; ++c)
-            o[(size_t)(i * (p - 1) + c)] = inv ? (wpow(t, (i64)i * (c + 1)) + q - wpow(t, p - c - 1)) % q : wpow(t, (i64)c * (i + 1));
-        }, (size_t)(p - 1) * (p - 1));
-        // crtTwiddle diagonal over the phi(pp) digit (crt.cpp:35-81)
-        int ctw_off = -1;
-        if (mprime > 1)
-          ctw_off = per_comp([&](int t, std::vector<u64>& o) {
-            RuView r{rutab, T, t};
-            for (i64 i0 = 0; i0 < mprime; ++i0)
-              for (int i1 = 0; i1 < p - 1; ++i1)
-                o[(size_t)(i0 * (p - 1) + i1)] = r(digit_rev(p, e - 1, i0) * (i1 + 1));
-          }, (size_t)phi);
-        // dftTwiddle diagonals, one per DFT stage of DFT_{p^(e-1)} (crt.cpp:84-126, 459-516)
-        const int e1 = e - 1;
-        const i64 rts1 = rts * (p - 1);
-        auto dft_diag = [&](int ecur, i64 dim, i64 twidRuStride) -> int {
-          if (dim / p <= 1) return -1;
-          return per_comp([&](int t, std::vector<u64>& o) {
-            RuView r{rutab, T, t};
-            for (i64 c = 0; c < dim; ++c) {
-              i64 i0 = c / p, i1 = c % p;
-              o[(size_t)c] = (i0 == 0 || i1 == 0) ? 1 % qs[(size_t)t] : r(digit_rev(p, ecur - 1, i0) * i1 * twidRuStride);
-            }
-          }, (size_t)dim);
-        };
-        if (!inv) {
-          if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off, mat_crt);
-          if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
-          i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
-          int ecur = e1;
-          for (int i = 0; i < e1; ++i) {
-            const i64 rtsDim = rts1 * rtsScale;
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
-            int off = dft_diag(ecur, ltsScale * p, twidRuStride);
-            if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
-            ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
-          }
-        } else {
-          i64 ltsScale = 1, rtsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, twidRuStride = e1 > 0 ? p * ipow(p, e1 - 1) : 0;
-          int ecur = 1;
-          for (int i = 0; i < e1; ++i) {
-            const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
-            int off = dft_diag(ecur, ltsScaleP, twidRuStride);
-            if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
-            pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
-            ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
-          }
-          if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
-          if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off, mat_crt);
-        }
-      }
-      rts *= phi;
-    }
-    // mhat^-1 (crt.cpp:573-579)
-    const int mh_off = per_comp([&](int t, std::vector<u64>& o) { o[0] = (u64)P.mhatinv[(size_t)t]; }, 1);
-    crtinv.diag(mh_off, 1, 1);
+  {
+    ModRing ring{P, qs, P.has_crt};
+    build_crt_programs(pps, ring, pool, &crt, &crtinv, split2 ? &crt_odd : nullptr, split2 ? &crtinv_odd : nullptr);
   }
   const int orad_off = per_comp([&](int t, std::vector<u64>& o) { o[0] = P.oddrad_inv[(size_t)t]; }, 1);
 
@@ -292,6 +334,47 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   P.consts_per_comp = pool.size();
   P.host_consts.clear();
   for (int t = 0; t < T; ++t) P.host_consts.insert(P.host_consts.end(), pool.pool[(size_t)t].begin(), pool.pool[(size_t)t].end());
+
+  // ---- floating-point side -----------------------------------------------
+  // tensorCRTC / tensorCRTInvC (crt.cpp:583-598) are the SAME templates as the Z_q transforms
+  // instantiated at Complex (ppcrt/ppcrtinv over tensorFuserCRT): the stage lists above are
+  // reused as they are with a second constant pool over C whose offsets coincide.
+  {
+    PoolBuilderT<std::complex<double>> cpool(1);
+    cpool.add({{std::complex<double>(1.0, 0.0)}});
+    ProgBuilder d0, d1, d2, d3;
+    CplxRing ring{pps, P.m};
+    build_crt_programs(pps, ring, cpool, &d0, &d1, split2 ? &d2 : nullptr, split2 ? &d3 : nullptr);
+    P.host_cconsts.clear();
+    for (const auto& z : cpool.pool[0]) { P.host_cconsts.push_back(z.real()); P.host_cconsts.push_back(z.imag()); }
+  }
+  // tensorGaussianDec (random.cpp:19-64): per odd prime p the real (p-1) x (p-1) map
+  //   out[row] = (sum_{col=1}^{p-1} 2 c(row*col mod p) y[col-1]) / sqrt 2,
+  //   c(k) = Re omega_p^k for col <= p/2, Im omega_p^k for col > p/2, omega_p = exp(2 pi i / p)
+  // on every (p-1)-vector of axis k (lts * p^(e-1) blocks, stride rts: ppD, random.cpp:52-58).
+  {
+    ProgBuilder pb;
+    P.host_rconsts.assign(1, 1.0);
+    i64 rts = 1;
+    for (int k = 0; k < K; ++k) {
+      const int p = pps[(size_t)k].p, e = pps[(size_t)k].e;
+      if (p != 2) {
+        const int off = (int)P.host_rconsts.size();
+        for (int row = 0; row < p - 1; ++row)
+          for (int col = 1; col <= p - 1; ++col) {
+            const double ang = 2.0 * M_PI * (double)((row * col) % p) / (double)p;
+            P.host_rconsts.push_back(2.0 * (col <= (p >> 1) ? std::cos(ang) : std::sin(ang)));
+          }
+        pb.dense(ST_GAUSS, p, p - 1, rts, 0);
+        pb.st.back().mat_off = off;
+      }
+      rts *= totient_pp(p, e);
+    }
+    finish(pb.st);
+    P.prog_gauss.stages = pb.st;
+  }
+  P.float_ok = P.n <= 8192;
+  for (const auto& pe : pps) if (pe.p > 13) P.float_ok = false;
 
   P.is_pow2 = P.has_crt && K == 1 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
   P.pow2_part = P.has_crt && K >= 2 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
@@ -332,8 +415,10 @@ int plan_upload(Plan& P) {
   if ((rc = upload(&P.d_mod, mods))) return rc;
   if ((rc = upload(&P.d_consts, P.host_consts))) return rc;
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss};
   for (auto* sp : progs) if ((rc = upload_prog(*sp))) return rc;
+  if ((rc = upload(&P.d_cconsts, P.host_cconsts))) return rc;
+  if ((rc = upload(&P.d_rconsts, P.host_rconsts))) return rc;
   if ((rc = upload(&P.d_gcrt, P.gcrt))) return rc;
   if ((rc = upload(&P.d_ginvcrt, P.ginvcrt))) return rc;
 
@@ -400,11 +485,12 @@ int plan_upload(Plan& P) {
 
 void plan_free_device(Plan& P) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt);
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_cconsts); fr(P.d_rconsts);
+  P.d_cconsts = nullptr; P.d_rconsts = nullptr;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
   P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr;
   P.pow2 = Pow2Tables();

@@ -26,7 +26,8 @@ enum StageKind : int32_t {
   ST_GDEC = 7,     //                                            gDec (g.cpp:37-58)
   ST_GINVPOW = 8,  //                                            gInvPow (g.cpp:60-90)
   ST_GINVDEC = 9,  //                                            gInvDec (g.cpp:92-123)
-  ST_SCALE = 10    // out[x] = s * in[x]  (mhatInv crt.cpp:573-579, oddRad^-1 g.cpp:194-204)
+  ST_SCALE = 10,   // out[x] = s * in[x]  (mhatInv crt.cpp:573-579, oddRad^-1 g.cpp:194-204)
+  ST_GAUSS = 11    // real (p-1) x (p-1) map of tensorGaussianDec           primeD (random.cpp:19-50)
 };
 
 struct Stage {
@@ -96,6 +97,13 @@ struct Plan {
   bool is_pow2 = false;
   int device_id = -1;                       // HIP device the tables were uploaded to
   int mixed_cls = 0;                        // arithmetic/storage class of the vector interpreter (mixed.hip)
+  // floating-point side (floatpath.hip): the CRT stage lists over C — a second
+  // constant pool, (re, im) interleaved, same offsets as host_consts — and the real maps of
+  // tensorGaussianDec
+  std::vector<double> host_cconsts, host_rconsts;
+  double *d_cconsts = nullptr, *d_rconsts = nullptr;
+  StageProgram prog_gauss;
+  bool float_ok = false;                    // n <= 8192 and every prime <= 13 (one LDS-resident polynomial, register vectors)
   // Nothing in a plan is written after plan_upload(): per-call workspaces (the operand copy of the
   // unfused poly-mul, the HBM ping-pong ring of polynomials too large for LDS) are stream-ordered
   // allocations made by the call that needs them, so host threads and streams can share a plan.

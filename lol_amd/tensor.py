@@ -93,6 +93,8 @@ def lib():
     for nm in ("crt", "crtinv", "l", "linv", "mulgpow", "mulgdec", "divgpow", "divgdec", "mulgcrt", "divgcrt"):
         getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, i64]
     L.lolhip_mul_batch.argtypes = [vp, vp, vp, vp, i64]
+    for nm in ("crtc", "crtinvc", "gaussian_dec"):
+        getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, i64]
     L.lolhip_polymul_batch.argtypes = [vp, vp, vp, vp, vp, i64]
     L.lolhip_ctmul_crt_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64]
     L.lolhip_decompose_len.argtypes = [vp, i64]
@@ -354,6 +356,32 @@ class Plan:
         _check(lib().lolhip_polymul_batch(self._h, _stream(stream), _devptr(out), _devptr(a), _devptr(b), self._batch_t(a)))
         return out
 
+
+    # ---- floating-point members: float64, tolerance contract -----------
+    def _float_op(self, name, y, complex_):
+        """numpy in -> numpy out (staged through HBM); torch CUDA tensor -> in place."""
+        import torch
+        host = isinstance(y, np.ndarray)
+        want = torch.complex128 if complex_ else torch.float64
+        t = torch.from_numpy(np.ascontiguousarray(y, dtype=np.complex128 if complex_ else np.float64)).cuda() if host else y
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == want):
+            raise TypeError(f"expected a contiguous {want} CUDA tensor")
+        if t.numel() % self.n:
+            raise ValueError("tensor is not a whole number of polynomials")
+        _check(getattr(lib(), f"lolhip_{name}_batch")(self._h, _stream(None), t.data_ptr(), t.numel() // self.n))
+        return t.cpu().numpy() if host else t
+
+    def crtC(self, y):
+        """CRT over C (tensorCRTC, crt.cpp:583-586): complex128 [..., n]."""
+        return self._float_op("crtc", y, True)
+
+    def crtInvC(self, y):
+        """inverse CRT over C including mhat^-1 (tensorCRTInvC, crt.cpp:589-598)."""
+        return self._float_op("crtinvc", y, True)
+
+    def gaussianDec(self, y):
+        """iid real Gaussians [..., n] -> decoding-basis sample (tensorGaussianDec, random.cpp:61-64)."""
+        return self._float_op("gaussian_dec", y, False)
 
     # ---- ring-level pipelines of SymmSHE (include/lolhip.h, SURVEY.md 8f N1) -----------
     # numpy in -> numpy out (staged through HBM with torch); CUDA tensors in -> CUDA tensors out.

@@ -204,6 +204,54 @@ class CTRef:
             getattr(L, nm).argtypes = [i16, _i64p, hdim, pp, i16, _i64p]
         L.tensorGInvPowRq.restype = i16
         L.tensorGInvDecRq.restype = i16
+        # floating-point members (crt.cpp:583-598, random.cpp:61-64); Complex = {double re, im}
+        cp, cpp_ = C.c_void_p, C.POINTER(C.c_void_p)
+        L.tensorCRTC.argtypes = [i16, cp, hdim, pp, i16, cpp_]
+        L.tensorCRTInvC.argtypes = [i16, cp, hdim, pp, i16, cpp_, cp]
+        L.tensorGaussianDec.argtypes = [i16, cp, hdim, pp, i16, cpp_]
+        for nm in ("tensorCRTC", "tensorCRTInvC", "tensorGaussianDec"):
+            getattr(L, nm).restype = None
+
+    # ---- floating-point members: the reference's own code on complex roots omega = exp(2 pi i / m) ----
+    @staticmethod
+    def _cplx_ru(pps, inverse=False):
+        """ru[k][i] = omega_{pp_k}^{+-i} as complex128 (CPP.hs:422-442 at Complex Double)."""
+        keep = []
+        for p, e in pps:
+            pp = p ** e
+            ang = 2.0 * np.pi * np.arange(pp) / pp
+            keep.append(np.ascontiguousarray(np.cos(ang) + (-1j if inverse else 1j) * np.sin(ang), dtype=np.complex128))
+        arr = (C.c_void_p * max(1, len(keep)))(*[k.ctypes.data for k in keep])
+        return arr, keep
+
+    def crtc(self, pps, y):
+        n = lm.totient_pps(pps)
+        y = np.ascontiguousarray(y, dtype=np.complex128).copy().reshape(-1, n)
+        ru, keep = self._cplx_ru(pps)
+        pa = _pp_array(pps)
+        for b in range(y.shape[0]):
+            self.lib.tensorCRTC(1, y[b].ctypes.data, n, pa, len(pps), ru)
+        return y
+
+    def crtinvc(self, pps, y):
+        n = lm.totient_pps(pps)
+        m = lm.value_pps(pps)
+        y = np.ascontiguousarray(y, dtype=np.complex128).copy().reshape(-1, n)
+        ru, keep = self._cplx_ru(pps, inverse=True)
+        mh = np.array([1.0 / (m // 2 if m % 2 == 0 else m)], dtype=np.complex128)
+        pa = _pp_array(pps)
+        for b in range(y.shape[0]):
+            self.lib.tensorCRTInvC(1, y[b].ctypes.data, n, pa, len(pps), ru, mh.ctypes.data)
+        return y
+
+    def gaussian_dec(self, pps, y):
+        n = lm.totient_pps(pps)
+        y = np.ascontiguousarray(y, dtype=np.float64).copy().reshape(-1, n)
+        ru, keep = self._cplx_ru(pps)
+        pa = _pp_array(pps)
+        for b in range(y.shape[0]):
+            self.lib.tensorGaussianDec(1, y[b].ctypes.data, n, pa, len(pps), ru)
+        return y
 
     def _each(self, P: Params, y, fn):
         y = np.ascontiguousarray(y, dtype=np.int64).copy().reshape(-1, P.n, P.T)
