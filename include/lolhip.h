@@ -275,6 +275,29 @@ LOLHIP_API int64_t lolhip_rqproduct_write(uint32_t m, const int64_t *qs, int T, 
 LOLHIP_API int64_t lolhip_kshint_read(const uint8_t *buf, int64_t len, uint32_t *m, int64_t *qs, int cap_T, int *T,
                                       int *L, int *K, int64_t *xs, int64_t cap_xs);
 
+/* The remaining messages of lol/Lol.proto and lol-apps/SHE.proto, same conventions:
+ *  r_read          message R { m = 1; repeated sint64 xs = 2 }: integer coefficients, decoding basis.  Returns n.
+ *  secretkey_read  message SecretKey { R sk = 1; double v = 2 } (SHE.proto:9).  Returns n.
+ *  kqproduct_read  message KqProduct / Kq (`repeated double xs`): xs [n][T] doubles.  Returns n.
+ *  linearrq_read   message LinearRq { e = 1; r = 2; repeated RqProduct coeffs = 3 } (Lol.proto:11): the
+ *                  values of an E-linear function on the relative decoding basis, xs [C][n][T]; after l
+ *                  and crt, the ys of lolhip_evallin_batch.  Returns n; xs = NULL queries the sizes.
+ *  kshint_write    the inverse of kshint_read; gad_a/gad_b = the two words of the TypeRep fingerprint.
+ *  tunnelhint_read message TunnelHint (SHE.proto:26): e, r, s, p and the byte ranges (offset, length
+ *                  into buf) of the embedded LinearRq and KSHints, for the readers above.  Returns the
+ *                  number of KSHints. */
+LOLHIP_API int64_t lolhip_r_read(const uint8_t *buf, int64_t len, uint32_t *m, int64_t *xs, int64_t cap_xs);
+LOLHIP_API int64_t lolhip_secretkey_read(const uint8_t *buf, int64_t len, uint32_t *m, double *v, int64_t *xs, int64_t cap_xs);
+LOLHIP_API int64_t lolhip_kqproduct_read(const uint8_t *buf, int64_t len, uint32_t *m, int64_t *qs, int cap_T, int *T,
+                                         double *xs, int64_t cap_xs);
+LOLHIP_API int64_t lolhip_linearrq_read(const uint8_t *buf, int64_t len, uint32_t *e, uint32_t *r, int *C, uint32_t *m,
+                                        int64_t *qs, int cap_T, int *T, int64_t *xs, int64_t cap_xs);
+LOLHIP_API int64_t lolhip_kshint_write(uint32_t m, const int64_t *qs, int T, int L, int K, const int64_t *xs, int64_t n,
+                                       uint64_t gad_a, uint64_t gad_b, uint8_t *out, int64_t cap);
+LOLHIP_API int64_t lolhip_tunnelhint_read(const uint8_t *buf, int64_t len, uint32_t *e, uint32_t *r, uint32_t *s, uint64_t *p,
+                                          int64_t *func_off, int64_t *func_len, int64_t *hint_off, int64_t *hint_len,
+                                          int cap_hints);
+
 /* number of HIP devices visible (0 without a GPU); never initialises a context */
 LOLHIP_API int lolhip_device_count(void);
 LOLHIP_API const char *lolhip_version(void);

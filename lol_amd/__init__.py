@@ -10,8 +10,10 @@ calls raise.
 """
 from .tensor import (  # noqa: F401
     LolHipError, NoDeviceError, Plan, Ext, lib, lib_path, device_count, good_q, factor_pps,
-    rqproduct_read, rqproduct_write, kshint_read,
+    rqproduct_read, rqproduct_write, kshint_read, kshint_write, r_read, secretkey_read, kqproduct_read,
+    linearrq_read, tunnelhint_read,
 )
 
 __all__ = ["LolHipError", "NoDeviceError", "Plan", "Ext", "lib", "lib_path", "device_count",
-           "good_q", "factor_pps", "rqproduct_read", "rqproduct_write", "kshint_read"]
+           "good_q", "factor_pps", "rqproduct_read", "rqproduct_write", "kshint_read", "kshint_write", "r_read",
+           "secretkey_read", "kqproduct_read", "linearrq_read", "tunnelhint_read"]

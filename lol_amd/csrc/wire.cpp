@@ -3,6 +3,10 @@
 // Messages (lol/Lol.proto, proto2):
 //   message Rq        { required uint32 m = 1; required uint64 q = 2; repeated sint64 xs = 3; }
 //   message RqProduct { repeated Rq rqlist = 1; }
+//   message R         { required uint32 m = 1; repeated sint64 xs = 2; }
+//   message Kq / KqProduct: as Rq / RqProduct with `repeated double xs`
+//   message LinearRq  { required uint32 e = 1; required uint32 r = 2; repeated RqProduct coeffs = 3; }
+// and of lol-apps/SHE.proto: SecretKey, RqPolynomial, KSHint (read and write), TunnelHint.
 // Conventions (lol/Crypto/Lol/Types/IZipVector.hs:127-205, Lol.proto:18-20): one Rq per
 // modulus of the RNS tuple, first component first; xs are the coefficients in the DECODING
 // basis, written as centred lifts in [-q/2, q/2) (toProto: `LP.lift`), read back with `reduce`.
@@ -210,6 +214,234 @@ int64_t lolhip_kshint_read(const uint8_t* buf, int64_t len, uint32_t* m_out, int
       for (int t = 0; t < T0; ++t) if (q1[(size_t)t] != q0[(size_t)t]) return LOLHIP_ERR_INVALID;
     }
   return n;
+}
+
+}  // extern "C"
+
+// ---- the remaining messages of Lol.proto / SHE.proto ---------------------
+
+namespace {
+
+// one length-delimited sub-message: returns false on a malformed length
+bool sub(Reader& rd, const uint8_t*& b, int64_t& l) {
+  uint64_t v;
+  if (!rd.varint(v) || (uint64_t)(rd.end - rd.p) < v) return false;
+  b = rd.p; l = (int64_t)v; rd.p += v;
+  return true;
+}
+
+// message R { required uint32 m = 1; repeated sint64 xs = 2; }
+int64_t parse_r(const uint8_t* buf, int64_t len, uint32_t* m_out, int64_t* xs, int64_t cap) {
+  Reader rd{buf, buf + len};
+  bool has_m = false;
+  int64_t n = 0;
+  auto put = [&](int64_t v) { if (xs && n < cap) xs[n] = v; ++n; };
+  while (rd.p < rd.end) {
+    uint64_t key, v;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 0) { if (!rd.varint(v)) return LOLHIP_ERR_INVALID; if (m_out) *m_out = (uint32_t)v; has_m = true; }
+    else if (field == 2 && wt == 0) { if (!rd.varint(v)) return LOLHIP_ERR_INVALID; put(unzigzag(v)); }
+    else if (field == 2 && wt == 2) {
+      const uint8_t* b; int64_t l;
+      if (!sub(rd, b, l)) return LOLHIP_ERR_INVALID;
+      Reader in{b, b + l};
+      while (in.p < in.end) { uint64_t z; if (!in.varint(z)) return LOLHIP_ERR_INVALID; put(unzigzag(z)); }
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  if (!has_m) return LOLHIP_ERR_INVALID;
+  if (xs && n > cap) return LOLHIP_ERR_INVALID;
+  return n;
+}
+
+inline double f64_at(const uint8_t* p) { double d; std::memcpy(&d, p, 8); return d; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t lolhip_r_read(const uint8_t* buf, int64_t len, uint32_t* m, int64_t* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  return parse_r(buf, len, m, xs, cap_xs);
+}
+
+// message SecretKey { required R sk = 1; required double v = 2; }  (SHE.proto:9)
+int64_t lolhip_secretkey_read(const uint8_t* buf, int64_t len, uint32_t* m, double* v_out, int64_t* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  Reader rd{buf, buf + len};
+  const uint8_t* rb = nullptr; int64_t rl = 0;
+  bool has_v = false;
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 2) { if (!sub(rd, rb, rl)) return LOLHIP_ERR_INVALID; }
+    else if (field == 2 && wt == 1) { if (rd.end - rd.p < 8) return LOLHIP_ERR_INVALID; if (v_out) *v_out = f64_at(rd.p); rd.p += 8; has_v = true; }
+    else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  if (!rb || !has_v) return LOLHIP_ERR_INVALID;
+  return parse_r(rb, rl, m, xs, cap_xs);
+}
+
+// message KqProduct { repeated Kq kqlist = 1; }, Kq { m = 1; q = 2; repeated double xs = 3; }
+// -> xs [n][T] doubles (decoding basis, as written), qs [T].  Returns n.
+int64_t lolhip_kqproduct_read(const uint8_t* buf, int64_t len, uint32_t* m_out, int64_t* qs, int cap_T, int* T_out,
+                              double* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  struct KqView { uint32_t m = 0; uint64_t q = 0; bool hm = false, hq = false; std::vector<double> xs; };
+  std::vector<KqView> list;
+  Reader rd{buf, buf + len};
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 2) {
+      const uint8_t* b; int64_t l;
+      if (!sub(rd, b, l)) return LOLHIP_ERR_INVALID;
+      list.emplace_back();
+      KqView& k = list.back();
+      Reader in{b, b + l};
+      while (in.p < in.end) {
+        uint64_t k2, v;
+        if (!in.varint(k2)) return LOLHIP_ERR_INVALID;
+        const uint32_t f2 = (uint32_t)(k2 >> 3), w2 = (uint32_t)(k2 & 7);
+        if (f2 == 1 && w2 == 0) { if (!in.varint(v)) return LOLHIP_ERR_INVALID; k.m = (uint32_t)v; k.hm = true; }
+        else if (f2 == 2 && w2 == 0) { if (!in.varint(v)) return LOLHIP_ERR_INVALID; k.q = v; k.hq = true; }
+        else if (f2 == 3 && w2 == 1) { if (in.end - in.p < 8) return LOLHIP_ERR_INVALID; k.xs.push_back(f64_at(in.p)); in.p += 8; }
+        else if (f2 == 3 && w2 == 2) {
+          const uint8_t* pb; int64_t pl;
+          if (!sub(in, pb, pl) || pl % 8) return LOLHIP_ERR_INVALID;
+          for (int64_t i = 0; i < pl; i += 8) k.xs.push_back(f64_at(pb + i));
+        } else if (!in.skip(w2)) return LOLHIP_ERR_INVALID;
+      }
+      if (!k.hm || !k.hq) return LOLHIP_ERR_INVALID;
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  const int T = (int)list.size();
+  if (T == 0) return LOLHIP_ERR_INVALID;
+  const int64_t n = (int64_t)list[0].xs.size();
+  for (const KqView& k : list) if (k.m != list[0].m || (int64_t)k.xs.size() != n) return LOLHIP_ERR_INVALID;
+  if (m_out) *m_out = list[0].m;
+  if (T_out) *T_out = T;
+  if (qs) { if (cap_T < T) return LOLHIP_ERR_INVALID; for (int t = 0; t < T; ++t) qs[t] = (int64_t)list[(size_t)t].q; }
+  if (xs) {
+    if (cap_xs < n * T) return LOLHIP_ERR_INVALID;
+    for (int t = 0; t < T; ++t) for (int64_t j = 0; j < n; ++j) xs[j * T + t] = list[(size_t)t].xs[(size_t)j];
+  }
+  return n;
+}
+
+// message LinearRq { required uint32 e = 1; required uint32 r = 2; repeated RqProduct coeffs = 3; }
+// (Lol.proto:11): the values of an E-linear function on the decoding basis of R/E — after l and
+// crt, the ys of lolhip_evallin_batch.  xs [C][n][T] (decoding basis, canonical residues); n, T,
+// qs are those of the output ring's RqProducts.  Returns n; xs = NULL queries e, r, C, m, T, qs.
+int64_t lolhip_linearrq_read(const uint8_t* buf, int64_t len, uint32_t* e_out, uint32_t* r_out, int* C_out,
+                             uint32_t* m_out, int64_t* qs, int cap_T, int* T_out, int64_t* xs, int64_t cap_xs) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  struct Span { const uint8_t* p; int64_t n; };
+  std::vector<Span> cs;
+  bool he = false, hr = false;
+  Reader rd{buf, buf + len};
+  while (rd.p < rd.end) {
+    uint64_t key, v;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 0) { if (!rd.varint(v)) return LOLHIP_ERR_INVALID; if (e_out) *e_out = (uint32_t)v; he = true; }
+    else if (field == 2 && wt == 0) { if (!rd.varint(v)) return LOLHIP_ERR_INVALID; if (r_out) *r_out = (uint32_t)v; hr = true; }
+    else if (field == 3 && wt == 2) { const uint8_t* b; int64_t l; if (!sub(rd, b, l)) return LOLHIP_ERR_INVALID; cs.push_back(Span{b, l}); }
+    else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  if (!he || !hr) return LOLHIP_ERR_INVALID;
+  const int C = (int)cs.size();
+  if (C_out) *C_out = C;
+  if (C == 0) { if (T_out) *T_out = 0; return 0; }
+  uint32_t m0 = 0; int T0 = 0;
+  std::vector<int64_t> q0(cap_T > 0 ? (size_t)cap_T : 16), q1(q0.size());
+  const int64_t n = lolhip_rqproduct_read(cs[0].p, cs[0].n, &m0, q0.data(), (int)q0.size(), &T0, nullptr, 0);
+  if (n < 0) return n;
+  if (m_out) *m_out = m0;
+  if (T_out) *T_out = T0;
+  if (qs) { if (cap_T < T0) return LOLHIP_ERR_INVALID; for (int t = 0; t < T0; ++t) qs[t] = q0[(size_t)t]; }
+  if (!xs) return n;
+  if (cap_xs < (int64_t)C * n * T0) return LOLHIP_ERR_INVALID;
+  for (int i = 0; i < C; ++i) {
+    uint32_t m1 = 0; int T1 = 0;
+    const int64_t n1 = lolhip_rqproduct_read(cs[(size_t)i].p, cs[(size_t)i].n, &m1, q1.data(), (int)q1.size(), &T1,
+                                             xs + (int64_t)i * n * T0, n * T0);
+    if (n1 < 0) return n1;
+    if (n1 != n || m1 != m0 || T1 != T0) return LOLHIP_ERR_INVALID;
+    for (int t = 0; t < T0; ++t) if (q1[(size_t)t] != q0[(size_t)t]) return LOLHIP_ERR_INVALID;
+  }
+  return n;
+}
+
+// KSHint writer: xs [L][K][n][T] decoding-basis residues -> bytes (the inverse of lolhip_kshint_read;
+// gad_a / gad_b are the two words of the gadget's GHC fingerprint, TypeRep, copied through).
+int64_t lolhip_kshint_write(uint32_t m, const int64_t* qs, int T, int L, int K, const int64_t* xs, int64_t n,
+                            uint64_t gad_a, uint64_t gad_b, uint8_t* out, int64_t cap) {
+  if (!qs || T < 1 || L < 1 || K < 1 || n < 0 || (n > 0 && !xs)) return LOLHIP_ERR_INVALID;
+  std::vector<int64_t> prod((size_t)L * K), poly((size_t)L);
+  int64_t total = 0;
+  for (int j = 0; j < L; ++j) {
+    int64_t pl = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t b = lolhip_rqproduct_write(m, qs, T, xs + ((int64_t)j * K + k) * n * T, n, nullptr, 0);
+      if (b < 0) return b;
+      prod[(size_t)j * K + k] = b;
+      pl += 1 + varint_len((uint64_t)b) + b;
+    }
+    poly[(size_t)j] = pl;
+    total += 1 + varint_len((uint64_t)pl) + pl;
+  }
+  const int64_t gl = 1 + varint_len(gad_a) + 1 + varint_len(gad_b);
+  total += 1 + varint_len((uint64_t)gl) + gl;
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  for (int j = 0; j < L; ++j) {
+    *o++ = 0x0A; put_varint(o, (uint64_t)poly[(size_t)j]);             // hint = 1
+    for (int k = 0; k < K; ++k) {
+      *o++ = 0x0A; put_varint(o, (uint64_t)prod[(size_t)j * K + k]);   // coeffs = 1
+      const int64_t w = lolhip_rqproduct_write(m, qs, T, xs + ((int64_t)j * K + k) * n * T, n, o, prod[(size_t)j * K + k]);
+      if (w < 0) return w;
+      o += w;
+    }
+  }
+  *o++ = 0x12; put_varint(o, (uint64_t)gl);                            // gad = 2
+  *o++ = 0x08; put_varint(o, gad_a);
+  *o++ = 0x10; put_varint(o, gad_b);
+  return (int64_t)(o - out);
+}
+
+// message TunnelHint { LinearRq func = 1; repeated KSHint hint = 2; e = 3; r = 4; s = 5; p = 6; }
+// (SHE.proto:26): one ring switch.  Returns the number of KSHints and the byte ranges
+// (offset, length into buf) of the embedded LinearRq and of up to cap_hints KSHints, to be handed
+// to lolhip_linearrq_read / lolhip_kshint_read.
+int64_t lolhip_tunnelhint_read(const uint8_t* buf, int64_t len, uint32_t* e, uint32_t* r, uint32_t* s, uint64_t* p,
+                               int64_t* func_off, int64_t* func_len, int64_t* hint_off, int64_t* hint_len, int cap_hints) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  Reader rd{buf, buf + len};
+  bool hf = false, he = false, hr = false, hs = false, hp = false;
+  int64_t nh = 0;
+  while (rd.p < rd.end) {
+    uint64_t key, v;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if ((field == 1 || field == 2) && wt == 2) {
+      const uint8_t* b; int64_t l;
+      if (!sub(rd, b, l)) return LOLHIP_ERR_INVALID;
+      if (field == 1) { if (func_off) *func_off = b - buf; if (func_len) *func_len = l; hf = true; }
+      else { if (nh < cap_hints) { if (hint_off) hint_off[nh] = b - buf; if (hint_len) hint_len[nh] = l; } ++nh; }
+    } else if (field >= 3 && field <= 6 && wt == 0) {
+      if (!rd.varint(v)) return LOLHIP_ERR_INVALID;
+      if (field == 3) { if (e) *e = (uint32_t)v; he = true; }
+      else if (field == 4) { if (r) *r = (uint32_t)v; hr = true; }
+      else if (field == 5) { if (s) *s = (uint32_t)v; hs = true; }
+      else { if (p) *p = v; hp = true; }
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  if (!(hf && he && hr && hs && hp)) return LOLHIP_ERR_INVALID;        // all `required`
+  return nh;
 }
 
 }  // extern "C"

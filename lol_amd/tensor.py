@@ -122,6 +122,15 @@ def lib():
     L.lolhip_rqproduct_write.restype = i64
     L.lolhip_kshint_read.argtypes = [u8p, i64, C.POINTER(C.c_uint32), _i64p, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), _i64p, i64]
     L.lolhip_kshint_read.restype = i64
+    u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    L.lolhip_r_read.argtypes = [u8p, i64, u32p, _i64p, i64]
+    L.lolhip_secretkey_read.argtypes = [u8p, i64, u32p, f64p, _i64p, i64]
+    L.lolhip_kqproduct_read.argtypes = [u8p, i64, u32p, _i64p, ci, C.POINTER(ci), f64p, i64]
+    L.lolhip_linearrq_read.argtypes = [u8p, i64, u32p, u32p, C.POINTER(ci), u32p, _i64p, ci, C.POINTER(ci), _i64p, i64]
+    L.lolhip_kshint_write.argtypes = [C.c_uint32, _i64p, ci, ci, ci, _i64p, i64, C.c_uint64, C.c_uint64, u8p, i64]
+    L.lolhip_tunnelhint_read.argtypes = [u8p, i64, u32p, u32p, u32p, C.POINTER(C.c_uint64), _i64p, _i64p, _i64p, _i64p, ci]
+    for nm in ("r_read", "secretkey_read", "kqproduct_read", "linearrq_read", "kshint_write", "tunnelhint_read"):
+        getattr(L, f"lolhip_{nm}").restype = i64
     L.lolhip_device_count.restype = ci
     L.lolhip_version.restype = C.c_char_p
     L.lolhip_last_status.restype = ci
@@ -205,6 +214,90 @@ def kshint_read(data: bytes):
     xs = np.zeros((Lh.value, K.value, n, T.value), dtype=np.int64)
     _check(min(L_.lolhip_kshint_read(*args, xs.ctypes.data_as(_i64p), xs.size), 0))
     return int(m.value), [int(q) for q in qs[:T.value]], xs
+
+
+def _raw(data: bytes):
+    return (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+
+
+def r_read(data: bytes):
+    """Lol.proto `R` -> (m, xs[n]) integer decoding-basis coefficients."""
+    L_ = lib()
+    raw, m = _raw(data), C.c_uint32(0)
+    n = L_.lolhip_r_read(raw, len(data), C.byref(m), None, 0)
+    _check(min(n, 0))
+    xs = np.zeros(n, dtype=np.int64)
+    _check(min(L_.lolhip_r_read(raw, len(data), C.byref(m), xs.ctypes.data_as(_i64p), n), 0))
+    return int(m.value), xs
+
+
+def secretkey_read(data: bytes):
+    """SHE.proto `SecretKey` -> (m, scaled variance v, sk[n])."""
+    L_ = lib()
+    raw, m, v = _raw(data), C.c_uint32(0), C.c_double(0)
+    n = L_.lolhip_secretkey_read(raw, len(data), C.byref(m), C.byref(v), None, 0)
+    _check(min(n, 0))
+    xs = np.zeros(n, dtype=np.int64)
+    _check(min(L_.lolhip_secretkey_read(raw, len(data), C.byref(m), C.byref(v), xs.ctypes.data_as(_i64p), n), 0))
+    return int(m.value), float(v.value), xs
+
+
+def kqproduct_read(data: bytes):
+    """Lol.proto `KqProduct` -> (m, [q_t], xs [n][T] float64)."""
+    L_ = lib()
+    raw, m, T = _raw(data), C.c_uint32(0), C.c_int(0)
+    qs = np.zeros(16, dtype=np.int64)
+    n = L_.lolhip_kqproduct_read(raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T), None, 0)
+    _check(min(n, 0))
+    xs = np.zeros((n, T.value), dtype=np.float64)
+    _check(min(L_.lolhip_kqproduct_read(raw, len(data), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T),
+                                        xs.ctypes.data_as(C.POINTER(C.c_double)), xs.size), 0))
+    return int(m.value), [int(q) for q in qs[:T.value]], xs
+
+
+def linearrq_read(data: bytes):
+    """Lol.proto `LinearRq` -> (e, r, m_out, [q_t], xs [C][n][T]) decoding basis, canonical residues."""
+    L_ = lib()
+    raw = _raw(data)
+    e, r, m, Cn, T = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_int(0)
+    qs = np.zeros(16, dtype=np.int64)
+    args = (raw, len(data), C.byref(e), C.byref(r), C.byref(Cn), C.byref(m), qs.ctypes.data_as(_i64p), 16, C.byref(T))
+    n = L_.lolhip_linearrq_read(*args, None, 0)
+    _check(min(n, 0))
+    xs = np.zeros((Cn.value, n, T.value), dtype=np.int64)
+    _check(min(L_.lolhip_linearrq_read(*args, xs.ctypes.data_as(_i64p), xs.size), 0))
+    return int(e.value), int(r.value), int(m.value), [int(q) for q in qs[:T.value]], xs
+
+
+def kshint_write(m: int, qs, xs, gad=(0, 0)) -> bytes:
+    """xs [L][K][n][T] decoding-basis residues -> SHE.proto `KSHint` bytes (gad = TypeRep words)."""
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    Lh, K, n, T = xs.shape
+    qa = np.ascontiguousarray(qs, dtype=np.int64)
+    L_ = lib()
+    args = (m, qa.ctypes.data_as(_i64p), T, Lh, K, xs.ctypes.data_as(_i64p), n, int(gad[0]), int(gad[1]))
+    need = L_.lolhip_kshint_write(*args, None, 0)
+    _check(min(need, 0))
+    buf = (C.c_uint8 * max(need, 1))()
+    wrote = L_.lolhip_kshint_write(*args, buf, need)
+    _check(min(wrote, 0))
+    return bytes(buf[:wrote])
+
+
+def tunnelhint_read(data: bytes):
+    """SHE.proto `TunnelHint` -> dict(e, r, s, p, func = linearrq_read(...), hints = [kshint_read(...)])."""
+    L_ = lib()
+    raw = _raw(data)
+    e, r, s, p = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    fo, fl = C.c_int64(0), C.c_int64(0)
+    nh = L_.lolhip_tunnelhint_read(raw, len(data), C.byref(e), C.byref(r), C.byref(s), C.byref(p), C.byref(fo), C.byref(fl), None, None, 0)
+    _check(min(nh, 0))
+    ho, hl = np.zeros(max(nh, 1), dtype=np.int64), np.zeros(max(nh, 1), dtype=np.int64)
+    _check(min(L_.lolhip_tunnelhint_read(raw, len(data), C.byref(e), C.byref(r), C.byref(s), C.byref(p), C.byref(fo), C.byref(fl),
+                                         ho.ctypes.data_as(_i64p), hl.ctypes.data_as(_i64p), nh), 0))
+    return {"e": int(e.value), "r": int(r.value), "s": int(s.value), "p": int(p.value),
+            "func": linearrq_read(data[fo.value: fo.value + fl.value]),
+            "hints": [kshint_read(data[int(o): int(o) + int(l)]) for o, l in zip(ho[:nh], hl[:nh])]}
 
 
 def _np(a):

@@ -40,12 +40,36 @@ def _messages():
     ks = fd.message_type.add(name="KSHint")
     ks.field.add(name="hint", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqPolynomial")
     ks.field.add(name="gad", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_REQUIRED, type_name=".crypto.proto.lol.TypeRep")
+    rmsg = fd.message_type.add(name="R")
+    rmsg.field.add(name="m", number=1, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    rmsg.field.add(name="xs", number=2, type=F.TYPE_SINT64, label=F.LABEL_REPEATED)
+    kq = fd.message_type.add(name="Kq")
+    kq.field.add(name="m", number=1, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    kq.field.add(name="q", number=2, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
+    kq.field.add(name="xs", number=3, type=F.TYPE_DOUBLE, label=F.LABEL_REPEATED)
+    kqp = fd.message_type.add(name="KqProduct")
+    kqp.field.add(name="kqlist", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.Kq")
+    lin = fd.message_type.add(name="LinearRq")
+    lin.field.add(name="e", number=1, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    lin.field.add(name="r", number=2, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    lin.field.add(name="coeffs", number=3, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.RqProduct")
+    sk = fd.message_type.add(name="SecretKey")                      # lol-apps/SHE.proto
+    sk.field.add(name="sk", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REQUIRED, type_name=".crypto.proto.lol.R")
+    sk.field.add(name="v", number=2, type=F.TYPE_DOUBLE, label=F.LABEL_REQUIRED)
+    th = fd.message_type.add(name="TunnelHint")
+    th.field.add(name="func", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REQUIRED, type_name=".crypto.proto.lol.LinearRq")
+    th.field.add(name="hint", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".crypto.proto.lol.KSHint")
+    for i, nm in enumerate(("e", "r", "s")):
+        th.field.add(name=nm, number=3 + i, type=F.TYPE_UINT32, label=F.LABEL_REQUIRED)
+    th.field.add(name="p", number=6, type=F.TYPE_UINT64, label=F.LABEL_REQUIRED)
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = getattr(message_factory, "GetMessageClass", None)
     cls = (lambda n: get(pool.FindMessageTypeByName("crypto.proto.lol." + n))) if get else \
           (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("crypto.proto.lol." + n)))
     _messages.KSHint = cls("KSHint")
+    for nm in ("R", "KqProduct", "LinearRq", "SecretKey", "TunnelHint"):
+        setattr(_messages, nm, cls(nm))
     return cls("RqProduct"), cls("RqProductPacked")
 
 
@@ -140,3 +164,86 @@ def test_kshint_read():
     broken = msg.SerializeToString()[:-30]
     with pytest.raises(lol_amd.LolHipError):
         lol_amd.kshint_read(broken[:40])
+
+
+def _fill_product(prod, m, qs, xs):
+    for t, q in enumerate(qs):
+        rq = prod.rqlist.add()
+        rq.m, rq.q = m, q
+        rq.xs.extend(_lift(v, q) for v in xs[:, t])
+
+
+def test_kshint_write_is_the_inverse_and_byte_identical():
+    import lol_amd
+    _messages()
+    m, qs = 16, [97, lm.first_good_q(16, 2 ** 40)]
+    R = Params(lm.factor_pps(m), qs)
+    rng = np.random.default_rng(4)
+    Lh, K = 2, 3
+    xs = np.stack([np.stack([R.random(rng, 1)[0] for _ in range(K)]) for _ in range(Lh)])
+    data = lol_amd.kshint_write(m, qs, xs, gad=(11, 2 ** 63 + 5))
+    msg = _messages.KSHint()
+    msg.ParseFromString(data)
+    assert (msg.gad.a, msg.gad.b) == (11, 2 ** 63 + 5) and len(msg.hint) == Lh and len(msg.hint[0].coeffs) == K
+    assert msg.SerializeToString() == data
+    assert np.array_equal(lol_amd.kshint_read(data)[2], xs)
+
+
+def test_r_secretkey_kq_linearrq_tunnelhint_against_google_protobuf():
+    """The remaining messages of Lol.proto / SHE.proto, written by google.protobuf, read by liblolhip."""
+    import lol_amd
+    _messages()
+    rng = np.random.default_rng(9)
+    # R and SecretKey: small signed integers, decoding basis
+    sk = _messages.SecretKey()
+    sk.sk.m, sk.v = 12, 2.5
+    vals = [int(v) for v in rng.integers(-5, 6, size=4)]
+    sk.sk.xs.extend(vals)
+    assert lol_amd.secretkey_read(sk.SerializeToString()) [0:2] == (12, 2.5)
+    assert lol_amd.secretkey_read(sk.SerializeToString())[2].tolist() == vals
+    m_, xs_ = lol_amd.r_read(sk.sk.SerializeToString())
+    assert m_ == 12 and xs_.tolist() == vals
+    with pytest.raises(lol_amd.LolHipError):
+        lol_amd.secretkey_read(sk.sk.SerializeToString())             # an R is not a SecretKey: v is required
+    # KqProduct
+    kqp = _messages.KqProduct()
+    want = rng.standard_normal((6, 2))
+    for t, q in enumerate((97, 193)):
+        k = kqp.kqlist.add()
+        k.m, k.q = 9, q
+        k.xs.extend(float(v) for v in want[:, t])
+    m_, qs_, got = lol_amd.kqproduct_read(kqp.SerializeToString())
+    assert (m_, qs_) == (9, [97, 193]) and np.array_equal(got, want)
+    # LinearRq: E = O_4 in R = O_16 -> S = O_24 say; coeffs are RqProducts over S
+    ms, qs = 24, [97, lm.first_good_q(24, 2 ** 40)]
+    S = Params(lm.factor_pps(ms), qs)
+    coeffs = np.stack([S.random(rng, 1)[0] for _ in range(4)])
+    lin = _messages.LinearRq()
+    lin.e, lin.r = 4, 16
+    for c in coeffs:
+        _fill_product(lin.coeffs.add(), ms, qs, c)
+    e, r, m2, qs2, xs = lol_amd.linearrq_read(lin.SerializeToString())
+    assert (e, r, m2, qs2) == (4, 16, ms, qs) and np.array_equal(xs, coeffs)
+    # TunnelHint around it, with two KSHints
+    th = _messages.TunnelHint()
+    th.func.CopyFrom(lin)
+    th.e, th.r, th.s, th.p = 4, 16, 24, 2 ** 40 + 15
+    hints = []
+    for h in range(2):
+        ks = th.hint.add()
+        ks.gad.a, ks.gad.b = h, h + 1
+        x = np.stack([np.stack([S.random(rng, 1)[0] for _ in range(2)]) for _ in range(3)])
+        hints.append(x)
+        for j in range(3):
+            pl = ks.hint.add()
+            for k in range(2):
+                _fill_product(pl.coeffs.add(), ms, qs, x[j, k])
+    d = lol_amd.tunnelhint_read(th.SerializeToString())
+    assert (d["e"], d["r"], d["s"], d["p"]) == (4, 16, 24, 2 ** 40 + 15)
+    assert np.array_equal(d["func"][4], coeffs) and len(d["hints"]) == 2
+    for h in range(2):
+        assert np.array_equal(d["hints"][h][2], hints[h])
+    raw = th.SerializeToString()
+    for bad in (raw[:-3], raw[:20], lin.SerializeToString()):         # truncated; a LinearRq is not a TunnelHint
+        with pytest.raises(lol_amd.LolHipError):
+            lol_amd.tunnelhint_read(bad)
