@@ -74,7 +74,7 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
   const ModCtx ms = mod[s];
-  const QK32 qk(ms.q);
+  const QK32 qk(ms.q, std::bool_constant<(NT >= 64)>{});
   const u32 mu32 = (u32)(ms.mu >> 32);                   // floor(2^32 / q_s)
 
   const u64 slab = (u64)B * n * T;                       // elements per [B][n][T] slab

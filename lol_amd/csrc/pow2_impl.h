@@ -154,11 +154,19 @@ template <int AR> using VT = std::conditional_t<AR >= 2, u32, u64>;
 // Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
 struct QK {
   u64 q, nq, q2, nq2, q4, nq4;
-  __device__ __forceinline__ explicit QK(u64 q_) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {}
+  // UNIFORM: the modulus is the same for every lane of the wave (SGPRs), else per lane (VGPRs)
+  template <bool UNIFORM>
+  __device__ __forceinline__ QK(u64 q_, std::bool_constant<UNIFORM>) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {
+    // opaque to the optimiser: x + nq4 must stay ONE v_lshl_add_u64, not be rewritten as the
+    // two-instruction borrow chain x - q4
+    if constexpr (UNIFORM) asm volatile("" : "+s"(nq), "+s"(nq2), "+s"(nq4));
+    else asm volatile("" : "+v"(nq), "+v"(nq2), "+v"(nq4));
+  }
 };
 struct QK32 {
   u32 q, q2;
-  __device__ __forceinline__ explicit QK32(u64 q_) : q((u32)q_), q2(2 * (u32)q_) {}
+  template <bool UNIFORM>
+  __device__ __forceinline__ QK32(u64 q_, std::bool_constant<UNIFORM>) : q((u32)q_), q2(2 * (u32)q_) {}
 };
 template <int AR> using QKT = std::conditional_t<AR >= 2, QK32, QK>;
 
@@ -751,7 +759,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
-  const QKT<AR> qk(mod[t].q);
+  const QKT<AR> qk(mod[t].q, std::bool_constant<(NT >= 64 || TU)>{});
   // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
   // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
   // stores are dropped by the hardware range check.

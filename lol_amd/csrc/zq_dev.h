@@ -95,28 +95,15 @@ LH_D u64 mad64(u32 a, u32 b, u64 c) {
   return (u64)a * (u64)b + c;
 #endif
 }
-LH_D u64 add64(u64 a, u64 b) {
-  u64 d;
-  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-LH_D u64 shl1_add64(u64 a, u64 b) {
-  u64 d;
-  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-// the same two with a WAVE-UNIFORM addend read straight from an SGPR pair (the per-modulus
-// constants): one VGPR pair less per constant in a kernel that sits at the register limit
-LH_D u64 add64u(u64 a, u64 b_uniform) {
-  u64 d;
-  asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
-  return d;
-}
-LH_D u64 shl1_add64u(u64 a, u64 b_uniform) {
-  u64 d;
-  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
-  return d;
-}
+// 64-bit adds.  Plain C: hipcc selects v_lshl_add_u64 for these by itself — PROVIDED a uniform
+// addend is not a compile-time-visible negation (x + (0 - m) becomes a two-instruction
+// v_sub_co/v_subb; the per-modulus constants are laundered once in QK, pow2_impl.h).  As
+// single-instruction inline asm each of these cost an s_nop: the hazard recognizer pads every
+// asm block boundary (1,460 s_nop per wave in the round-1 fused kernel, 630 now).
+LH_D u64 add64(u64 a, u64 b) { return a + b; }
+LH_D u64 shl1_add64(u64 a, u64 b) { return (a << 1) + b; }
+LH_D u64 add64u(u64 a, u64 b_uniform) { return a + b_uniform; }
+LH_D u64 shl1_add64u(u64 a, u64 b_uniform) { return (a << 1) + b_uniform; }
 LH_D u32 lo32(u64 x) { return (u32)x; }
 LH_D u32 hi32(u64 x) { return (u32)(x >> 32); }
 
@@ -158,8 +145,8 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
       : [wph] "v"(hi32(wp)), [wpl] "v"(lo32(wp)), [ylo] "v"(lo32(y)), [yhi] "v"(hi32(y)),
         [wl] "v"(lo32(w)), [wh] "v"(hi32(w)), [nql] "s"(lo32(nq)), [nqh] "s"(hi32(nq))
       : "vcc", "v118", "v119", "v120", "v121", "v122", "v123");
-  u32 th;
-  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  u32 th = hi32(t) + lo32(h);
+  asm("" : "+v"(th));          // keeps it ONE v_add_u32 (else: t + (h << 32) as v_mov + v_lshl_add_u64)
   return ((u64)th << 32) | lo32(t);
 #elif LOLHIP_ASM_MAD == 3
   // Two asm blocks per product (hipcc pads every separate asm statement that writes an SGPR
@@ -184,8 +171,8 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
       : "v"(lo32(w)), "v"(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),
         "s"(lo32(nq)), "s"(hi32(nq)), "v"(init)      // nq: wave-uniform, one SGPR operand per mad
       : "vcc");
-  u32 th;
-  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  u32 th = hi32(t) + lo32(h);
+  asm("" : "+v"(th));          // keeps it ONE v_add_u32 (else: t + (h << 32) as v_mov + v_lshl_add_u64)
   return ((u64)th << 32) | lo32(t);
 #else
   const u32 ah = __umulhi(hi32(wp), lo32(y));
@@ -197,8 +184,8 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
   h = mad64(hi32(w), lo32(y), h);
   h = mad64(lo32(Q), hi32(nq), h);
   h = mad64(hi32(Q), lo32(nq), h);
-  u32 th;
-  asm("v_add_u32 %0, %1, %2" : "=v"(th) : "v"(hi32(t)), "v"(lo32(h)));
+  u32 th = hi32(t) + lo32(h);
+  asm("" : "+v"(th));          // keeps it ONE v_add_u32 (else: t + (h << 32) as v_mov + v_lshl_add_u64)
   return ((u64)th << 32) | lo32(t);
 #endif
 }

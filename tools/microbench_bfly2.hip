@@ -96,7 +96,7 @@ __device__ __forceinline__ void inv(u64& X, u64& Y, u64 w, u64 wp, const K& k, c
 template <int V, bool INV>
 __global__ void __launch_bounds__(256) k_thr(u64* out, unsigned long long* cyc, const u64* tw, const K* kp) {
   const K k = *kp;
-  const QK qk(k.q);
+  const QK qk(k.q, std::true_type{});
   u64 y[CH];
   for (int i = 0; i < CH; i++) y[i] = (((threadIdx.x + i + 1) * 0x9E3779B97F4A7C15ull) >> 4) % k.q;
   const u64* t = tw + 2 * (threadIdx.x & 63);
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_thr(u64* out, unsigned long long* cyc, 
 template <int V, bool INV>
 __global__ void k_chk(u64* xy, const u64* tw, const K* kp, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
-  const K k = *kp; const QK qk(k.q);
+  const K k = *kp; const QK qk(k.q, std::true_type{});
   u64 X = xy[2 * i], Y = xy[2 * i + 1];
   if constexpr (INV) inv<V>(X, Y, tw[2 * i], tw[2 * i + 1], k, qk); else fwd<V>(X, Y, tw[2 * i], tw[2 * i + 1], k, qk);
   xy[2 * i] = X; xy[2 * i + 1] = Y;
