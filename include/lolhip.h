@@ -177,6 +177,18 @@ LOLHIP_API int lolhip_coeffs_batch      (const lolhip_ext *x, void *stream, int6
 LOLHIP_API int lolhip_evallin_batch(const lolhip_ext *x_er, const lolhip_ext *x_es, void *stream,
                                     const int64_t *r_dec, const int64_t *ys_crt, int64_t *out,
                                     int64_t *work, int64_t B);
+/* tunnel (lol-apps SymmSHE.hs:549-570), the body after `toMSD . absorbGFactors`: for a linear
+ * ciphertext [c0, c1] over R' (c0_dec in the decoding basis, c1_pow in the powerful basis, both
+ * [B][n_R][T]),
+ *     c0' = evalLin f c0;  c1s = coeffsPow c1 :: [E'];  c1' = sum_i switch hints_i (embed c1s_i)
+ *     out = const c0' + c1'      [2][B][n_S][T], CRT basis of S'
+ * ys_crt as for lolhip_evallin_batch; hints [n_R/n_E][L][2][n_S][T] (one KSHint per relative
+ * powerful-basis element, CRT basis, L = lolhip_decompose_len of the S' plan); base as for
+ * lolhip_keyswitch_batch.  work: lolhip_tunnel_work_len(...) int64 of device scratch. */
+LOLHIP_API int64_t lolhip_tunnel_work_len(const lolhip_ext *x_er, const lolhip_ext *x_es, int64_t base, int64_t B);
+LOLHIP_API int lolhip_tunnel_batch(const lolhip_ext *x_er, const lolhip_ext *x_es, void *stream,
+                                   const int64_t *c0_dec, const int64_t *c1_pow, const int64_t *ys_crt,
+                                   const int64_t *hints, int64_t base, int64_t *out, int64_t *work, int64_t B);
 /* host index tables: which 0 extIndicesPowDec[n] 1 extIndicesCRT[n'] 2 embedPow[n'] (-1 = zero)
  * 3 embedDec[n'] (-1 zero, bit 30 = negate) 4 baseIndicesCRT[n'] (Tensor.hs:426-468)
  * 5 extIndicesCoeffs[n'/n][n] flattened (Tensor.hs:472-477) */

@@ -412,20 +412,22 @@ int lolhip_knapsack_batch(const lolhip_plan* p, void* stream, const int64_t* xs_
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
-int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2_pow, int64_t base,
-                           const int64_t* hint, int K, const int64_t* addend, int64_t* out, int64_t* work, int64_t B) {
-  int rc = need_device(p); if (rc) return rc;
-  if (!p->P.has_crt) return LOLHIP_ERR_NO_CRT;
+}  // extern "C"
+
+namespace {
+// `switch` on one plan: the fused single-pass kernel where it applies, else decompose -> crt -> knapsack
+int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int64_t base, const int64_t* hint, int K,
+                   const int64_t* addend, int64_t* out, int64_t* work, int64_t B) {
+  if (!P.has_crt) return LOLHIP_ERR_NO_CRT;
   DecompParams d;
-  rc = make_decomp(p->P, base, d); if (rc) return rc;
+  int rc = make_decomp(P, base, d); if (rc) return rc;
   if (K < 1 || K > 3 || B < 0 || (B > 0 && (!c2_pow || !hint || !out || !work))) return LOLHIP_ERR_INVALID;
   if (B == 0) return LOLHIP_OK;
-  const Plan& P = p->P;
   // one fused pass when the plan is in the 32-bit class of the m = 2^k path (every q_t < 2^30)
   if (P.is_pow2 && P.pow2.arith32 == 2 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !getenv("LOLHIP_KEYSWITCH_UNFUSED")) {
     KeySwitchLaunch l;
-    l.stream = (hipStream_t)stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;
+    l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;
     l.T = P.T; l.L = P.pow2.L; l.tw_fwd32 = P.pow2.d_tw_fwd32; l.mod = P.d_mod; l.dp = d;
     l.magic32 = 1;
     if (base >= 2) {
@@ -435,11 +437,19 @@ int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2
     }
     return launch_keyswitch_fused(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
-  if (launch_decompose((hipStream_t)stream, c2_pow, work, B, p->P.n, d, p->P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
-  rc = lolhip_crt_batch(p, stream, work, (int64_t)d.L * B);          // all L*B digit polynomials in one launch
+  if (launch_decompose(stream, c2_pow, work, B, P.n, d, P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
+  rc = do_crt(P, stream, work, (int64_t)d.L * B, false);                 // all L*B digit polynomials in one launch
   if (rc) return rc;
-  return launch_knapsack((hipStream_t)stream, work, d.L, hint, K, addend, out, B, p->P.n, p->P.T, p->P.d_mod)
-                 == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+  return launch_knapsack(stream, work, d.L, hint, K, addend, out, B, P.n, P.T, P.d_mod) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+}
+}  // namespace
+
+extern "C" {
+
+int lolhip_keyswitch_batch(const lolhip_plan* p, void* stream, const int64_t* c2_pow, int64_t base,
+                           const int64_t* hint, int K, const int64_t* addend, int64_t* out, int64_t* work, int64_t B) {
+  int rc = need_device(p); if (rc) return rc;
+  return keyswitch_impl(p->P, (hipStream_t)stream, c2_pow, base, hint, K, addend, out, work, B);
 }
 
 int lolhip_rescale_drop_batch(const lolhip_plan* p, void* stream, const int64_t* c, int64_t* out, int64_t B) {
@@ -565,6 +575,57 @@ int lolhip_evallin_batch(const lolhip_ext* x_er, const lolhip_ext* x_es, void* s
   return launch_knapsack((hipStream_t)s, tmp_s, (int)rel, ys_crt, 1, nullptr, out, B, PS->n, PS->T, PS->d_mod)
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
+int64_t lolhip_tunnel_work_len(const lolhip_ext* x_er, const lolhip_ext* x_es, int64_t base, int64_t B) {
+  if (!x_er || !x_es || B < 0) return LOLHIP_ERR_INVALID;
+  DecompParams d;
+  int rc = make_decomp(*x_es->X.hi, base, d); if (rc) return rc;
+  const ExtPlan &ER = x_er->X, &ES = x_es->X;
+  const i64 rel = ER.host.phi2 / ER.host.phi;
+  const int T = ER.lo->T;
+  return rel * B * (ER.host.phi + ES.host.phi2) * T + (i64)d.L * B * ES.host.phi2 * T;
+}
+
+// tunnel (SymmSHE.hs:549-570), the body after toMSD . absorbGFactors: with [c0, c1] the linear
+// ciphertext over R',
+//   c0' = evalLin f c0;   c1s = coeffsPow c1 :: [E'];   c1' = sum_i switch hints_i (embed c1s_i)
+//   result = const c0' + c1'     (a linear ciphertext over S', CRT basis)
+// as a composition of the batch kernels: evalLin (coeffs gather, embedDec, l, crt, knapsack), then
+// ONE coeffs gather and ONE embedPow over all n_R/n_E coefficient vectors, then one key switch
+// per coefficient accumulating into the two output slabs.
+int lolhip_tunnel_batch(const lolhip_ext* x_er, const lolhip_ext* x_es, void* stream, const int64_t* c0_dec,
+                        const int64_t* c1_pow, const int64_t* ys_crt, const int64_t* hints, int64_t base,
+                        int64_t* out, int64_t* work, int64_t B) {
+  if (!x_er || !x_es) return LOLHIP_ERR_INVALID;
+  const ExtPlan &ER = x_er->X, &ES = x_es->X;
+  if (!ER.d_coeffs || !ES.d_embed_pow) return LOLHIP_ERR_NO_DEVICE;
+  if (ER.host.phi != ES.host.phi || ER.lo->T != ES.lo->T || ER.lo->qs != ES.lo->qs) return LOLHIP_ERR_INVALID;
+  if (B < 0 || (B > 0 && (!c0_dec || !c1_pow || !ys_crt || !hints || !out || !work))) return LOLHIP_ERR_INVALID;
+  if (B == 0) return LOLHIP_OK;
+  const Plan& PS = *ES.hi;
+  DecompParams d;
+  int rc = make_decomp(PS, base, d); if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const i64 rel = ER.host.phi2 / ER.host.phi;
+  const int T = PS.T;
+  const i64 nS = ES.host.phi2, nE = ER.host.phi;
+  const size_t slabS = (size_t)B * nS * T;
+  // c0' into out[0]; out[1] starts at zero
+  rc = lolhip_evallin_batch(x_er, x_es, stream, c0_dec, ys_crt, out, work, B); if (rc) return rc;
+  if (hipMemsetAsync(out + slabS, 0, slabS * sizeof(int64_t), s) != hipSuccess) return LOLHIP_ERR_HIP;
+  // coefficient vectors of c1 over the relative powerful basis, embedded into S' (powerful basis)
+  int64_t* tmp_e = work;                                   // [rel][B][n_E][T]
+  int64_t* tmp_s = work + rel * B * nE * T;                // [rel][B][n_S][T]
+  int64_t* ks_work = tmp_s + rel * B * nS * T;             // [L][B][n_S][T]
+  rc = lolhip_coeffs_batch(x_er, stream, tmp_e, c1_pow, B); if (rc) return rc;
+  rc = lolhip_embed_pow_batch(x_es, stream, tmp_s, tmp_e, rel * B); if (rc) return rc;
+  const size_t hint_i = (size_t)d.L * 2 * nS * T;          // one coefficient's hint: [L][2][n_S][T]
+  for (i64 i = 0; i < rel; ++i) {
+    rc = keyswitch_impl(PS, s, tmp_s + (size_t)i * slabS, base, hints + (size_t)i * hint_i, 2, out, out, ks_work, B);
+    if (rc) return rc;
+  }
+  return LOLHIP_OK;
+}
+
 int lolhip_embed_pow_batch(const lolhip_ext* x, void* s, int64_t* hi_out, const int64_t* lo_in, int64_t B) {
   return ext_gather(x, s, hi_out, lo_in, B, x ? x->X.d_embed_pow : nullptr, true);
 }

@@ -109,6 +109,9 @@ def lib():
     for nm in ("twace_powdec", "twace_crt", "embed_pow", "embed_dec", "embed_crt", "coeffs"):
         getattr(L, f"lolhip_{nm}_batch").argtypes = [vp, vp, vp, vp, i64]
     L.lolhip_evallin_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64]
+    L.lolhip_tunnel_work_len.argtypes = [vp, vp, i64, i64]
+    L.lolhip_tunnel_work_len.restype = i64
+    L.lolhip_tunnel_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64]
     L.lolhip_ext_table.argtypes = [vp, ci, _i32p, i64]
     L.lolhip_ext_table.restype = i64
     L.lolhip_op_host.argtypes = [vp, ci, _i64p, _i64p, i64]
@@ -618,6 +621,21 @@ class Ext:
         out = torch.empty((B, S.n, S.T), dtype=torch.int64, device=r_dec.device)
         _check(lib().lolhip_evallin_batch(self._h, es._h, _stream(stream), _devptr(r_dec), _devptr(ys_crt),
                                           _devptr(out), _devptr(work), B))
+        return Plan._unstage(host, out)
+
+    def tunnel(self, es: "Ext", c0_dec, c1_pow, ys_crt, hints, base, stream=None):
+        """SymmSHE `tunnel` after toMSD . absorbGFactors (SymmSHE.hs:549-570): self = E' in R', es = E' in S';
+        [c0 (decoding basis), c1 (powerful basis)] over R' -> [2][B][n_S][T] CRT-basis linear ciphertext over S'.
+        hints [n_R/n_E][L][2][n_S][T]."""
+        import torch
+        host, (c0_dec, c1_pow, ys_crt, hints) = Plan._stage(c0_dec, c1_pow, ys_crt, hints)
+        B, S = self.hi._batch_t(c0_dec), es.hi
+        wl = lib().lolhip_tunnel_work_len(self._h, es._h, int(base), B)
+        _check(min(wl, 0))
+        work = torch.empty((max(wl, 1),), dtype=torch.int64, device=c0_dec.device)
+        out = torch.empty((2, B, S.n, S.T), dtype=torch.int64, device=c0_dec.device)
+        _check(lib().lolhip_tunnel_batch(self._h, es._h, _stream(stream), _devptr(c0_dec), _devptr(c1_pow), _devptr(ys_crt),
+                                         _devptr(hints), int(base), _devptr(out), _devptr(work), B))
         return Plan._unstage(host, out)
 
     def twacePowDec(self, x, out=None, stream=None): return self._run(EXT_TWACE_POWDEC, "twace_powdec", x, False, out, stream)

@@ -166,3 +166,19 @@ def evallin(cpu: CpuRef, PE: Params, PR: Params, PS: Params, r_dec, ys_crt):
         y = np.ascontiguousarray(np.broadcast_to(np.asarray(ys_crt)[i], (B, PS.n, PS.T)))
         acc = _addmod(acc, cpu.mul(PS, np.ascontiguousarray(e), y).reshape(B, PS.n, PS.T), PS)
     return acc
+
+
+def tunnel(cpu: CpuRef, PE: Params, PR: Params, PS: Params, c0_dec, c1_pow, ys_crt, hints, base: int):
+    """SymmSHE.hs:549-570 after toMSD . absorbGFactors:
+         c0' = evalLin f c0;  c1s = coeffsPow c1;  c1' = sum (zipWith switch hints (embed <$> c1s))
+         result = const c0' + c1'
+    c0_dec, c1_pow [B][n_R][T]; hints [n_R/n_E][L][2][n_S][T] (CRT basis) -> [2][B][n_S][T], CRT basis of S'."""
+    B = np.asarray(c0_dec).shape[0]
+    out = np.zeros((2, B, PS.n, PS.T), dtype=np.int64)
+    out[0] = evallin(cpu, PE, PR, PS, c0_dec, ys_crt)
+    cs = cpu.coeffs(PE, PR, c1_pow)                                      # [rel][B][n_E][T]
+    for i in range(cs.shape[0]):
+        emb = cpu.embed_pow(PE, PS, cs[i]).reshape(B, PS.n, PS.T)
+        sw = keyswitch(cpu, PS, np.ascontiguousarray(emb), base, np.asarray(hints)[i])
+        out = ((out.astype(object) + sw) % _qs(PS)).astype(np.int64)
+    return out

@@ -630,6 +630,25 @@ def test_config4_mixed_radix_full_batch(gpu, cpuref):
         assert torch.equal(x, a)
         x = a.clone(); P.l(x); P.lInv(x)
         assert torch.equal(x, a)
+        # the fused one-launch poly-mul at full batch: samples against the oracle, then the ring
+        # laws over the whole batch (commutativity, the unit, c = a aliasing, squaring)
+        b = torch.randint(0, q, (B, R.n, 1), dtype=torch.int64, device="cuda", generator=g)
+        c = torch.empty_like(a)
+        P.polymul(a, b, out=c)
+        idx = [0, 1, 340, 341, 342, 1022, 1023]           # both ends and a workgroup-round boundary
+        assert np.array_equal(c[idx].cpu().numpy(), cpuref.polymul(R, a[idx].cpu().numpy(), b[idx].cpu().numpy()).reshape(len(idx), R.n, 1))
+        c2 = torch.empty_like(a)
+        P.polymul(b, a, out=c2)
+        assert torch.equal(c, c2)
+        one = torch.zeros_like(a); one[:, 0, 0] = 1
+        P.polymul(a, one, out=c2)
+        assert torch.equal(c2, a)
+        x = a.clone(); P.polymul(x, b, out=x)
+        assert torch.equal(x, c)
+        P.polymul(a, a, out=c2)                           # the a == b path skips the second transform
+        aa = a.clone(); P.polymul(a, aa, out=c)
+        assert torch.equal(c, c2)
+        assert np.array_equal(c2[[5]].cpu().numpy(), cpuref.polymul(R, a[[5]].cpu().numpy(), a[[5]].cpu().numpy()).reshape(1, R.n, 1))
 
 
 def test_config5_keyswitch_shapes(gpu, cpuref):

@@ -177,6 +177,27 @@ def test_gpu_evallin(gpu, cpuref, e, r, s, q):
         assert np.array_equal(XR.evalLin(XR, x, ident), GR.crt(GR.l(x)))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("e,r,s,q", EXT_CASES[:4] + [(128, 128 * 7, 128 * 13, 23297)])
+@pytest.mark.parametrize("base", [0, 16])
+def test_gpu_tunnel(gpu, cpuref, e, r, s, q, base):
+    """lolhip_tunnel_batch = evalLin on c0 + one key switch per relative powerful-basis coefficient of
+    c1, against the same composition of the restatement (SymmSHE.hs:549-570)."""
+    import math
+    qs = [q, lm.first_good_q(r * s // math.gcd(r, s), q)]
+    pe, pr, ps = (lm.factor_pps(m) for m in (e, r, s))
+    PE, PR, PS = (Params(p_, qs) for p_ in (pe, pr, ps))
+    GE, GR, GS = (gpu.Plan(p_, qs) for p_ in (pe, pr, ps))
+    XR, XS = gpu.Ext(GE, GR), gpu.Ext(GE, GS)
+    rng = np.random.default_rng(r + s + base)
+    B, rel, L = 2, PR.n // PE.n, sum(sr.digit_counts(PS, base))
+    c0, c1 = PR.random(rng, B), PR.random(rng, B)
+    ys = np.stack([PS.random(rng, 1)[0] for _ in range(rel)])
+    hints = np.stack([np.stack([np.stack([PS.random(rng, 1)[0] for _ in range(2)]) for _ in range(L)]) for _ in range(rel)])
+    got = XR.tunnel(XS, c0, c1, ys, hints, base)
+    assert np.array_equal(got, sr.tunnel(cpuref, PE, PR, PS, c0, c1, ys, hints, base))
+
+
 # ------------------------------------------------------------------------------------
 # GPU: liblolhip against the restatement, bit for bit
 # ------------------------------------------------------------------------------------
