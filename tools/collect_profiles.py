@@ -7,7 +7,7 @@ import csv, glob, json, os, re, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def pmc(dirname, pat="k_pow2"):
@@ -40,13 +40,14 @@ factor = known_kb / f_crt[0]
 read_b, write_b = f_pm[0] * factor * 1024, w_pm[0] * 1024
 alg = 3 * n * 8 * B
 traffic = {
+    "guide_x2_hbm_bytes_per_launch": int(f_pm[0] * 2 * 1024 + write_b),     # MI355X_MICROARCH.md: FETCH_SIZE x 2 for wide streaming reads
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section); values are KB. "
               "FETCH_SIZE under-reports wide streaming reads on gfx950; the factor is CALIBRATED on k_pow2<13,0> (crt in place), whose read "
               "volume is known exactly (4096*8192*8 B). WRITE_SIZE needs no correction (crt writes exactly that volume and WRITE_SIZE reports it).",
     "command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- tools/bench_kernels 14 1 4096 {crt,polymul} 5  (and --pmc WRITE_SIZE); tools/refresh_profiles.sh",
     "calibration_kernel": {"name": "k_pow2<13,0,1>", "known_read_KB": known_kb, "FETCH_SIZE_KB": f_crt[0], "factor": factor, "WRITE_SIZE_KB": w_crt[0]},
     "k_pow2_polymul": {"FETCH_SIZE_KB": f_pm[0], "WRITE_SIZE_KB": w_pm[0], "dispatches_averaged": f_pm[1], "read_bytes": int(read_b), "write_bytes": int(write_b),
-                       "note": "includes the register-spill scratch of the 64-bit fused kernel (one VGPR pair per thread, write-back through L2)"},
+                       "note": "round 2: the 64-bit fused kernel no longer spills (120 VGPRs); round 1 wrote one VGPR pair per thread to scratch (1.04x)"},
     "k_pow2_polymul_hbm_bytes_per_launch": int(read_b + write_b),
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": round((read_b + write_b) / alg, 4),
@@ -67,6 +68,39 @@ with open(os.path.join(DST, f"{tag}_pmc_polymul_sq.txt"), "w") as fh:
         fh.write(f"# LDS bank-conflict cycles / LDS active cycles = {sq['SQ_LDS_BANK_CONFLICT'] / sq['SQ_LDS_IDX_ACTIVE']:.3f}\n")
     if "SQ_ACTIVE_INST_VALU" in sq and "SQ_WAVE_CYCLES" in sq:
         fh.write(f"# VALU-active share of wave-cycles = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES']:.3f} (4 waves/SIMD: 0.25 = VALU always busy)\n")
+
+# 3b. config 4 (mixed radix): kernel trace, HBM traffic, SQ counters per (op, modulus)
+c4 = {"workload": "m = 15015 (n = 5760), batch 1024, tools/bench_kernels m15015 1 1024 <op> <iters> <qbits>",
+      "traffic_note": "FETCH_SIZE x 2 (MI355X_MICROARCH.md HBM section; 8-byte-per-lane buffer loads, so also quoted raw), WRITE_SIZE as read; KB per launch"}
+for qb in (30, 60):
+    for op in ("crt", "polymul"):
+        ent = {}
+        for f in glob.glob(os.path.join(SRC, f"c4_kt_{op}_{qb}", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_mixed" in r["Name"]:
+                    ent.update({"kernel": (re.search(r"k_mixed<[^>]*>", r["Name"]) or [r["Name"][:60]])[0], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])})
+        alg = (3 if op == "polymul" else 2) * 1024 * 5760 * 8
+        if "avg_ns" in ent:
+            ent["alg_bytes"] = alg
+            ent["frac_of_8TBps"] = round(alg / ent["avg_ns"] / 8000, 4)
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            v = pmc(f"c4_pmc_{op}_{qb}_{c}", "k_mixed")
+            if c in v:
+                ent[c + "_KB"] = round(v[c][0], 1)
+        if "FETCH_SIZE_KB" in ent and "WRITE_SIZE_KB" in ent:
+            ent["hbm_bytes_x2_rule"] = int((2 * ent["FETCH_SIZE_KB"] + ent["WRITE_SIZE_KB"]) * 1024)
+            ent["traffic_over_algorithmic_x2_rule"] = round(ent["hbm_bytes_x2_rule"] / alg, 3)
+        sqv = pmc(f"c4_sq_{op}_{qb}", "k_mixed")
+        ent["sq"] = {k: v[0] for k, v in sorted(sqv.items())}
+        if "SQ_INSTS_VALU" in ent["sq"] and "SQ_WAVES" in ent["sq"]:
+            ent["valu_instructions_per_wave"] = round(ent["sq"]["SQ_INSTS_VALU"] / ent["sq"]["SQ_WAVES"], 1)
+        c4[f"{op}_q{qb}"] = ent
+json.dump(c4, open(os.path.join(DST, f"{tag}_generic_c4.json"), "w"), indent=1)
+for name in ("microbench_ops.txt", "microbench_bfly2.txt"):
+    src = os.path.join(SRC, name)
+    if os.path.exists(src):
+        open(os.path.join(DST, f"{tag}_{name}"), "w").write(open(src).read())
 
 # 4. pipeline kernels
 pl = os.path.join(SRC, "pipelines.jsonl")
