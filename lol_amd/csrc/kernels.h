@@ -72,7 +72,8 @@ struct MixedLaunch {
   const u64* consts;
   int cpc;
   const ModCtx* mod;
-  int cls;               // 0: 64-bit residues; 1: every q < 2^32; 2: additionally 13 (q-1)^2 < 2^64
+  int cls;               // Plan::mixed_cls (plan.cpp): 0/1 exact division, 2/3 Montgomery with `consts` = the
+                         // pool pre-scaled by 2^32 / 2^64
   bool fused;
 };
 bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T);

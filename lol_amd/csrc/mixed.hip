@@ -15,9 +15,12 @@
 //       CLS 0  any q < 2^62:  64-bit residues in LDS, 128-bit dot-product accumulators;
 //       CLS 1  every q < 2^32: 32-bit residues in LDS and registers (half the LDS traffic and
 //              footprint), 32x32 products accumulated in 128 bits;
-//       CLS 2  additionally 13 (q-1)^2 < 2^64: the whole dot product accumulates in ONE 64-bit
-//              v_mad_u64_u32 chain and is reduced once by a Barrett step — the reference's own
-//              domain (q < 2^31.5, types.h:79-84) up to q < 2^30.15;
+//       CLS 3  64-bit residues, every q odd: as CLS 0 with the constants pre-scaled by 2^64 and ONE
+//              Montgomery reduction per dot product (~30 instructions against ~70);
+//       CLS 2  every q odd with 13 (q-1)^2 < 2^64: the whole dot product accumulates in ONE 64-bit
+//              v_mad_u64_u32 chain and is reduced once by a 9-instruction 32-bit Montgomery step
+//              (constants pre-scaled by 2^32) — the reference's own domain (q < 2^31.5,
+//              types.h:79-84) up to q < 2^30.15;
 //   * the poly-mul is ONE launch: a-hat waits in registers (each thread keeps the coefficients
 //     it loaded) while b goes through the same LDS buffer; b's global loads are issued before
 //     a's stages and land under them; HBM sees a and b once in and c once out (round 1: four
@@ -30,7 +33,8 @@ namespace {
 
 constexpr int KMAX = 16;            // coefficients a thread loads/stores: ppw * n <= KMAX * blockDim
 
-template <int CLS> using MV = std::conditional_t<CLS == 0, u64, u32>;
+template <int CLS> using MV = std::conditional_t<CLS == 0 || CLS == 3, u64, u32>;
+template <int CLS> constexpr bool wide() { return CLS == 0 || CLS == 3; }
 
 // x / v for x <= 8192 (every index here is below ppw * n <= 8192) from the plan's 2^40-scaled
 // reciprocal M = floor(2^40/v)+1: (M >> 8) + 1 is floor(2^32/v) + 1 or + 2, whose error times x
@@ -40,12 +44,12 @@ __device__ __forceinline__ int mdiv(int x, u64 M) {
 }
 
 template <int CLS> __device__ __forceinline__ MV<CLS> m_add(MV<CLS> a, MV<CLS> b, u64 q) {
-  if constexpr (CLS == 0) return addmod(a, b, q);
+  if constexpr (wide<CLS>()) return addmod(a, b, q);
   else if constexpr (CLS == 2) { const u32 s = a + b; return min(s, s - (u32)q); }   // q < 2^30.2: the sum fits a word
   else { const u64 s = (u64)a + b; return (u32)(s >= q ? s - q : s); }          // q may exceed 2^31: 33-bit sum
 }
 template <int CLS> __device__ __forceinline__ MV<CLS> m_sub(MV<CLS> a, MV<CLS> b, u64 q) {
-  if constexpr (CLS == 0) return submod(a, b, q);
+  if constexpr (wide<CLS>()) return submod(a, b, q);
   else if constexpr (CLS == 2) { const u32 d = a - b; return min(d, d + (u32)q); }   // a < b: d wraps high, d + q is the residue
   else return a >= b ? a - b : (u32)(a + (u32)q - b);
 }
@@ -56,8 +60,39 @@ __device__ __forceinline__ u32 barrett64(u64 x, const ModCtx& mc) {
   if (r >= mc.q) r -= mc.q;
   return (u32)r;
 }
-template <int CLS> __device__ __forceinline__ MV<CLS> m_mul(MV<CLS> a, u64 b, const ModCtx& mc) {
-  if constexpr (CLS == 0) return mulmod(a, b, mc);
+// Montgomery reduction of a 128-bit value T < 13 q^2 with q < 2^61 (so T / 2^64 < 13 q / 8):
+//   (T + ((T mod 2^64) * (-q^-1) mod 2^64) * q) / 2^64  =  T * 2^-64 mod q,  below 2.625 q < 2^63;
+// two conditional subtractions make it canonical.  ~25 instructions against ~70 for the exact
+// two-step 128-by-64 division; the 2^-64 is absorbed by constants pre-scaled on the host.
+__device__ __forceinline__ u64 redc128(unsigned __int128 T, const ModCtx& mc) {
+  const u64 lo = (u64)T, hi = (u64)(T >> 64);
+  const u64 m = lo * mc.nqinv;
+  u64 r = hi + __umul64hi(m, mc.q) + (lo != 0);      // lo + lo64(m q) = 0 mod 2^64: it carries iff lo != 0
+  r = csub(r, 2 * mc.q);
+  return csub(r, mc.q);
+}
+// 32-bit Montgomery reduction of T < 13 q^2 < 2^64 (class 2; q odd, q < 2^30.15):
+//   h = T >> 32 < 3.6 q fits a word; h >= 2q ? h - 2q : h changes T by a multiple of q and leaves h < 2q;
+//   m = (T mod 2^32) * (-q^-1) mod 2^32;  T + m q = 0 mod 2^32, and (T mod 2^32) + (m q mod 2^32)
+//   carries iff m != 0, so the carry folds into the high word of m q + (2^32 - 1): ONE v_mad_u64_u32;
+//   result h + ceil(m q / 2^32) < 3 q + 1 < 2^32 = T 2^-32 mod q, two min-subtractions to canonical.
+// 9 instructions against ~25 for a 64-bit Barrett step; the 2^-32 is absorbed by constants
+// pre-scaled on the host.
+__device__ __forceinline__ u32 redc64(u64 T, const ModCtx& mc) {
+  const u32 q = (u32)mc.q;
+  u32 h = (u32)(T >> 32);
+  h = min(h, h - 2 * q);
+  const u32 m = (u32)T * (u32)mc.nqinv;
+  u32 r = h + (u32)(((u64)m * q + 0xFFFFFFFFull) >> 32);
+  r = min(r, r - 2 * q);
+  return min(r, r - q);
+}
+// a * b mod q.  KPOOL: b comes from the constant pool (pre-scaled by 2^32 / 2^64 in classes 2 / 3);
+// otherwise b is a plain residue or small integer and those classes multiply exactly.
+template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(MV<CLS> a, u64 b, const ModCtx& mc) {
+  if constexpr (CLS == 3 && KPOOL) return redc128((unsigned __int128)a * b, mc);
+  else if constexpr (CLS == 2 && KPOOL) return redc64((u64)a * (u32)b, mc);
+  else if constexpr (wide<CLS>()) return mulmod(a, b, mc);
   else return barrett64((u64)a * (u32)b, mc);
 }
 
@@ -69,14 +104,15 @@ __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const u64* __res
     u64 acc = 0;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc += (u64)v[c] * (u32)row[c];      // one v_mad_u64_u32 per term; D (q-1)^2 < 2^64
-    return barrett64(acc, mc);
+    return redc64(acc, mc);
   } else {
     unsigned __int128 acc = 0;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
       if constexpr (CLS == 1) acc += (unsigned __int128)((u64)v[c] * (u32)row[c]);
-      else acc += (unsigned __int128)v[c] * row[c];
+      else acc += (unsigned __int128)v[c] * row[c];          // classes 0 and 3: 13 products below 2^124
     }
+    if constexpr (CLS == 3) return redc128(acc, mc);
     if (CLS == 1 && mc.q > 16) return (MV<CLS>)rem128((u64)(acc >> 64), (u64)acc, mc);   // high word < 16 < q: one division step
     return (MV<CLS>)reduce128((u64)(acc >> 64), (u64)acc, mc);
   }
@@ -143,7 +179,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
       for (int i = 0; i < D; ++i) {
         le = m_add<CLS>(le, v[i], q);
         const V re = m_sub<CLS>(tot, le, q);
-        o[i] = m_sub<CLS>(m_mul<CLS>(le, (u64)(st.p - 1 - i), mc), m_mul<CLS>(re, (u64)(i + 1), mc), q);
+        o[i] = m_sub<CLS>(m_mul<CLS, false>(le, (u64)(st.p - 1 - i), mc), m_mul<CLS, false>(re, (u64)(i + 1), mc), q);
       }
       break;
     }
@@ -151,7 +187,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
       V s = 0, tot = 0;
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        s = m_add<CLS>(s, m_mul<CLS>(v[c], (u64)(c + 1), mc), q);
+        s = m_add<CLS>(s, m_mul<CLS, false>(v[c], (u64)(c + 1), mc), q);
         tot = m_add<CLS>(tot, v[c], q);
       }
       const u64 pm = (u64)st.p;
@@ -159,7 +195,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
 #pragma unroll
       for (int i = 0; i < D; ++i) {
         le = m_add<CLS>(le, v[i], q);
-        o[i] = m_sub<CLS>(s, m_mul<CLS>(m_sub<CLS>(tot, le, q), pm, mc), q);
+        o[i] = m_sub<CLS>(s, m_mul<CLS, false>(m_sub<CLS>(tot, le, q), pm, mc), q);
       }
       break;
     }
@@ -216,7 +252,7 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
 }
 
 template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
-  if constexpr (CLS == 0) return canon_in(x, q);
+  if constexpr (wide<CLS>()) return canon_in(x, q);
   else return (u32)x + ((u32)q & (u32)(x >> 63));       // (-q, q) -> [0, q), q < 2^32
 }
 
@@ -229,7 +265,7 @@ template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
 // poly-mul keeps a-hat and b's loads live and gets 128 (4 waves/SIMD), as does the 64-bit class
 // (at 80 it spills: measured slower).
 template <int CLS, int MODE>
-__global__ void __launch_bounds__(512, (MODE == 0 && CLS >= 1) ? 6 : 4)
+__global__ void __launch_bounds__(512, (MODE == 0 && (CLS == 1 || CLS == 2)) ? 6 : 4)
 k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int ppw, i64 ngroups,
         const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
         const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod) {
@@ -303,7 +339,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       {
         const int x0 = fresh(tid);
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS>(ah[k], (u64)buf[x], mc); }
+        for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
       }
       __syncthreads();
       run_stages<CLS>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
@@ -350,12 +386,14 @@ hipError_t launch_mixed(const MixedLaunch& a) {
     switch (a.cls) {
       case 0: return launch_cls<0, 2>(a);
       case 1: return launch_cls<1, 2>(a);
+      case 3: return launch_cls<3, 2>(a);
       default: return launch_cls<2, 2>(a);
     }
   }
   switch (a.cls) {
     case 0: return launch_cls<0, 0>(a);
     case 1: return launch_cls<1, 0>(a);
+    case 3: return launch_cls<3, 0>(a);
     default: return launch_cls<2, 0>(a);
   }
 }

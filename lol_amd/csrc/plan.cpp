@@ -473,10 +473,32 @@ int plan_upload(Plan& P) {
   P.needs_scratch = 2 * (size_t)P.n * sizeof(u64) > 152 * 1024;
   // class of the vector interpreter: 32-bit residues when every q < 2^32; a dot product of up to 13
   // terms in ONE 64-bit accumulator when 13 (q-1)^2 < 2^64
-  P.mixed_cls = 2;
+  // class of the vector interpreter (mixed.hip):
+  //   2: every q odd with 13 (q-1)^2 < 2^64: 32-bit residues, one 64-bit accumulator per dot
+  //      product, constants pre-scaled by 2^32, one 32-bit Montgomery reduction per output;
+  //   1: every q < 2^32 otherwise (128-bit accumulators, exact division step);
+  //   3: 64-bit residues, every q odd and below 2^61: constants pre-scaled by 2^64, one 64-bit
+  //      Montgomery reduction per output;   0: anything else (exact two-step division).
+  bool fits32 = true, acc64 = true, odd = true, below61 = true;
   for (u64 q : P.qs) {
-    if ((unsigned __int128)13 * (q - 1) * (q - 1) >= ((unsigned __int128)1 << 64)) P.mixed_cls = P.mixed_cls < 1 ? P.mixed_cls : 1;
-    if (q >= ((u64)1 << 32)) P.mixed_cls = 0;
+    if (q >= ((u64)1 << 32)) fits32 = false;
+    if ((unsigned __int128)13 * (q - 1) * (q - 1) >= ((unsigned __int128)1 << 64)) acc64 = false;
+    if (!(q & 1)) odd = false;
+    if (q >= ((u64)1 << 61)) below61 = false;
+  }
+  P.mixed_cls = fits32 ? ((acc64 && odd) ? 2 : 1) : ((odd && below61) ? 3 : 0);
+  if (P.mixed_cls == 2 || P.mixed_cls == 3) {
+    const int sh = P.mixed_cls == 2 ? 32 : 64;
+    std::vector<u64> mont(P.host_consts.size());
+    for (int t = 0; t < T; ++t) {
+      const u64 q = P.qs[(size_t)t];
+      const u64 r = (u64)((((unsigned __int128)1) << sh) % q);
+      for (int i = 0; i < P.consts_per_comp; ++i) {
+        const size_t o = (size_t)t * P.consts_per_comp + i;
+        mont[o] = mulmod(P.host_consts[o] % q, r, q);
+      }
+    }
+    if ((rc = upload(&P.d_consts_mont, mont))) return rc;
   }
   HIPCK(hipGetDevice(&P.device_id));
   P.device = true;
@@ -485,8 +507,8 @@ int plan_upload(Plan& P) {
 
 void plan_free_device(Plan& P) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(P.d_mod); fr(P.d_consts); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_cconsts); fr(P.d_rconsts);
-  P.d_cconsts = nullptr; P.d_rconsts = nullptr;
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_consts_mont); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_cconsts); fr(P.d_rconsts);
+  P.d_cconsts = nullptr; P.d_rconsts = nullptr; P.d_consts_mont = nullptr;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,

@@ -37,6 +37,7 @@ struct ModCtx {
   u32 s;   // normalisation shift (>= 2 because q < 2^62)
   u32 pad;
   u64 mu;  // floor(2^64 / q) (Barrett constant of the 32-bit path)
+  u64 nqinv;  // -q^-1 mod 2^64 for odd q (Montgomery reduction in the mixed-radix 64-bit class), else 0
 };
 
 // Shoup pair: w and floor(w * 2^64 / q)
@@ -51,6 +52,12 @@ inline ModCtx make_modctx(u64 q) {
   c.v = (u64)((~(unsigned __int128)0) / c.d - ((unsigned __int128)1 << 64));
   c.pad = 0;
   c.mu = (u64)((((unsigned __int128)1) << 64) / q);
+  c.nqinv = 0;
+  if (q & 1) {                       // Newton iteration: x <- x (2 - q x), doubling the correct low bits
+    u64 x = q;                       // q * q = 1 mod 8: three correct bits
+    for (int i = 0; i < 6; ++i) x *= 2 - q * x;
+    c.nqinv = 0 - x;
+  }
   return c;
 }
 inline ShoupW make_shoup(u64 w, u64 q) {
