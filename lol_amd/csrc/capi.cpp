@@ -116,7 +116,7 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
   Pow2Launch l;
   l.stream = s; l.y = y; l.a = a; l.b = b; l.B = B; l.T = P.T; l.L = P.pow2.L;
   l.mod = P.d_mod;
-  if (P.pow2.arith32) {             // every modulus < 2^30 (class 2) or < 2^31 (class 3): 32-bit arithmetic
+  if (P.pow2.arith32) {             // every modulus < 2^27 (class 4), < 2^30 (2) or < 2^31 (3): 32-bit arithmetic
     l.arith = P.pow2.arith32; l.tw_fwd = P.pow2.d_tw_fwd32; l.tw_inv = P.pow2.d_tw_inv32; l.scale = P.pow2.d_scale32;
   } else {
     l.arith = 1;
@@ -424,11 +424,11 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
   if (K < 1 || K > 3 || B < 0 || (B > 0 && (!c2_pow || !hint || !out || !work))) return LOLHIP_ERR_INVALID;
   if (B == 0) return LOLHIP_OK;
   // one fused pass when the plan is in the 32-bit class of the m = 2^k path (every q_t < 2^30)
-  if (P.is_pow2 && P.pow2.arith32 == 2 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
+  if (P.is_pow2 && (P.pow2.arith32 == 2 || P.pow2.arith32 == 4) && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !getenv("LOLHIP_KEYSWITCH_UNFUSED")) {
     KeySwitchLaunch l;
     l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;
-    l.T = P.T; l.L = P.pow2.L; l.tw_fwd32 = P.pow2.d_tw_fwd32; l.mod = P.d_mod; l.dp = d;
+    l.T = P.T; l.L = P.pow2.L; l.tw_fwd32 = P.pow2.d_tw_fwd32; l.mod = P.d_mod; l.dp = d; l.arith = P.pow2.arith32;
     l.magic32 = 1;
     if (base >= 2) {
       int lg = 0;

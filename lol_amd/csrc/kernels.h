@@ -19,7 +19,7 @@ struct Pow2Launch {
   int L;
   const void *tw_fwd, *tw_inv, *scale;   // Shoup-pair tables: u64 pairs (arith 0/1) or u32 pairs (arith 2)
   const ModCtx* mod;
-  int arith;         // 2: every modulus < 2^30 (32-bit path); 1: every modulus < 2^61; 0: exact 64-bit
+  int arith;         // 4: every modulus < 2^27; 2: < 2^30; 3: < 2^31 (32-bit paths); 1: every modulus < 2^61; 0: exact 64-bit
 };
 // mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
 hipError_t launch_pow2(const Pow2Launch& a, int mode);
@@ -38,6 +38,7 @@ struct KeySwitchLaunch {
   const ModCtx* mod;
   DecompParams dp;
   uint32_t magic32;     // 32-bit invariant-divisor constant of dp.base
+  int arith;            // 2 or 4 (Pow2Launch::arith)
 };
 hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a);
 

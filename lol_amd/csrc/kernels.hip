@@ -23,12 +23,14 @@ extern template hipError_t launch_pow2_ar<0>(const Pow2Launch&, int);
 extern template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
 extern template hipError_t launch_pow2_ar<2>(const Pow2Launch&, int);
 extern template hipError_t launch_pow2_ar<3>(const Pow2Launch&, int);
+extern template hipError_t launch_pow2_ar<4>(const Pow2Launch&, int);
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (a.arith) {
     case 0: return launch_pow2_ar<0>(a, mode);
     case 1: return launch_pow2_ar<1>(a, mode);
     case 2: return launch_pow2_ar<2>(a, mode);
     case 3: return launch_pow2_ar<3>(a, mode);
+    case 4: return launch_pow2_ar<4>(a, mode);
     default: return hipErrorInvalidValue;
   }
 }
@@ -45,11 +47,11 @@ hipError_t launch_pow2(const Pow2Launch& a, int mode) {
 // accumulators (64-bit sums of raw products, 64 VGPRs) stay in registers in the transform's
 // output layout.
 // =============================================================================
-template <int L>
+template <int L, int AR>
 __global__ void __launch_bounds__(pow2_threads(L), 4)
 k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64* addend, i64* out, i64 B, int T,
             const u32* __restrict__ tw_fwd, const ModCtx* __restrict__ mod, DecompParams dp, u32 magic32, int xcd_map) {
-  constexpr int AR = 2;
+  static_assert(AR == 2 || AR == 4, "32-bit classes with [0,4q) / wide lazy forward ranges");
   constexpr int K = 2;
   using S = Sched<L>;
   using V = u32;
@@ -74,7 +76,7 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
   const ModCtx ms = mod[s];
-  const QK32 qk(ms.q, std::bool_constant<(NT >= 64)>{});
+  const QK32 qk(ms, std::bool_constant<(NT >= 64)>{});
   const u32 mu32 = (u32)(ms.mu >> 32);                   // floor(2^32 / q_s)
 
   const u64 slab = (u64)B * n * T;                       // elements per [B][n][T] slab
@@ -186,7 +188,7 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   }
 }
 
-template <int L>
+template <int L, int AR>
 static hipError_t launch_keyswitch_L(const KeySwitchLaunch& a) {
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);
@@ -200,31 +202,35 @@ static hipError_t launch_keyswitch_L(const KeySwitchLaunch& a) {
   if (lds_bytes > 64 * 1024) {
     static KernelDev tab[MAX_DEV];
     hipError_t e = kernel_dev_setup(tab, [&]() -> hipError_t {
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<L>),
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<L, AR>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_keyswitch<L>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream, a.c2, a.hint,
+  hipLaunchKernelGGL((k_keyswitch<L, AR>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream, a.c2, a.hint,
                      a.addend, a.out, a.B, a.T, a.tw_fwd32, a.mod, a.dp, a.magic32, xcd_map);
   return hipGetLastError();
 }
 
-hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a) {
+template <int AR>
+static hipError_t launch_keyswitch_ar(const KeySwitchLaunch& a) {
   switch (a.L) {
-    case 4: return launch_keyswitch_L<4>(a);
-    case 5: return launch_keyswitch_L<5>(a);
-    case 6: return launch_keyswitch_L<6>(a);
-    case 7: return launch_keyswitch_L<7>(a);
-    case 8: return launch_keyswitch_L<8>(a);
-    case 9: return launch_keyswitch_L<9>(a);
-    case 10: return launch_keyswitch_L<10>(a);
-    case 11: return launch_keyswitch_L<11>(a);
-    case 12: return launch_keyswitch_L<12>(a);
-    case 13: return launch_keyswitch_L<13>(a);
-    case 14: return launch_keyswitch_L<14>(a);
+    case 4: return launch_keyswitch_L<4, AR>(a);
+    case 5: return launch_keyswitch_L<5, AR>(a);
+    case 6: return launch_keyswitch_L<6, AR>(a);
+    case 7: return launch_keyswitch_L<7, AR>(a);
+    case 8: return launch_keyswitch_L<8, AR>(a);
+    case 9: return launch_keyswitch_L<9, AR>(a);
+    case 10: return launch_keyswitch_L<10, AR>(a);
+    case 11: return launch_keyswitch_L<11, AR>(a);
+    case 12: return launch_keyswitch_L<12, AR>(a);
+    case 13: return launch_keyswitch_L<13, AR>(a);
+    case 14: return launch_keyswitch_L<14, AR>(a);
     default: return hipErrorInvalidValue;
   }
+}
+hipError_t launch_keyswitch_fused(const KeySwitchLaunch& a) {
+  return a.arith == 4 ? launch_keyswitch_ar<4>(a) : launch_keyswitch_ar<2>(a);
 }
 
 // =============================================================================

@@ -448,7 +448,8 @@ int plan_upload(Plan& P) {
     if ((rc = upload(&P.pow2.d_tw_fwd, fwd))) return rc;
     if ((rc = upload(&P.pow2.d_tw_inv, inv))) return rc;
     if ((rc = upload(&P.pow2.d_scale, sc))) return rc;
-    P.pow2.arith32 = 2;
+    P.pow2.arith32 = 4;
+    for (u64 q : P.qs) { if (q >= (1ull << 27)) P.pow2.arith32 = 2; }
     for (u64 q : P.qs) { if (q >= (1ull << 30)) P.pow2.arith32 = 3; }
     for (u64 q : P.qs) { if (q >= (1ull << 31)) P.pow2.arith32 = 0; }
     if (P.pow2.arith32) {   // 32-bit Shoup pairs: wp = floor(w * 2^32 / q)

@@ -60,7 +60,7 @@ struct Pow2Tables {
   u64* d_scale = nullptr;          // [T][2]     Shoup pair of mhatInv
   // the same three tables as 32-bit Shoup pairs (w, floor(w*2^32/q)) when every q_t < 2^31
   uint32_t *d_tw_fwd32 = nullptr, *d_tw_inv32 = nullptr, *d_scale32 = nullptr;
-  int arith32 = 0;                 // 2: every q_t < 2^30; 3: every q_t < 2^31; 0: no 32-bit tables
+  int arith32 = 0;                 // 4: every q_t < 2^27; 2: < 2^30; 3: < 2^31; 0: no 32-bit tables
 };
 
 struct Plan {

@@ -149,12 +149,18 @@ constexpr int lpad(int x) { return x + (x >> 4); }
 //  AR = 1 (every q_t < 2^61): 64-bit residues, Shoup products with the 9-multiply approximate
 //         quotient (shoup_acc, result in [0,4q)); forward values in [0,8q), inverse in [0,4q).
 //  AR = 0 (2^61 <= q_t < 2^62): 10-multiply exact quotient, ranges [0,4q) / [0,2q).
+//  AR = 4 (every q_t < 2^27 — the reference's own benchmark moduli: 12289, 1017857, 1032193 ...):
+//         as AR = 2, but the forward transform does NO conditional subtraction: a level grows the
+//         bound by 2q, so after 14 levels values are below 29 q < 2^32; one Barrett step at the
+//         end.  7 instructions per forward butterfly against 9.
 template <int AR> using VT = std::conditional_t<AR >= 2, u32, u64>;
 
 // Per-modulus constants of the lazy butterflies (wave-uniform, live in SGPRs).
 struct QK {
   u64 q, nq, q2, nq2, q4, nq4;
   // UNIFORM: the modulus is the same for every lane of the wave (SGPRs), else per lane (VGPRs)
+  template <bool UNIFORM>
+  __device__ __forceinline__ QK(const ModCtx& mc, std::bool_constant<UNIFORM> u) : QK(mc.q, u) {}
   template <bool UNIFORM>
   __device__ __forceinline__ QK(u64 q_, std::bool_constant<UNIFORM>) : q(q_), nq(0 - q_), q2(2 * q_), nq2(0 - 2 * q_), q4(4 * q_), nq4(0 - 4 * q_) {
     // opaque to the optimiser: x + nq4 must stay ONE v_lshl_add_u64, not be rewritten as the
@@ -164,9 +170,9 @@ struct QK {
   }
 };
 struct QK32 {
-  u32 q, q2;
+  u32 q, q2, mu;       // mu = floor(2^32 / q): one-step Barrett of the wide lazy range of AR = 4
   template <bool UNIFORM>
-  __device__ __forceinline__ QK32(u64 q_, std::bool_constant<UNIFORM>) : q((u32)q_), q2(2 * (u32)q_) {}
+  __device__ __forceinline__ QK32(const ModCtx& mc, std::bool_constant<UNIFORM>) : q((u32)mc.q), q2(2 * (u32)mc.q), mu((u32)(mc.mu >> 32)) {}
 };
 template <int AR> using QKT = std::conditional_t<AR >= 2, QK32, QK>;
 
@@ -185,6 +191,11 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
   } else if constexpr (AR == 2) {
     const u32 x = csub32(X, k.q2);                    // [0,4q) -> [0,2q)
     const u32 t = shoup32(Y, w, wp, k.q);
+    X = x + t;
+    Y = x - t + k.q2;
+  } else if constexpr (AR == 4) {
+    const u32 t = shoup32(Y, w, wp, k.q);             // [0,2q) for ANY 32-bit Y
+    const u32 x = X;                                  // < B: both outputs < B + 2q, never wrapping below 29 q
     X = x + t;
     Y = x - t + k.q2;
   } else if constexpr (AR == 1) {
@@ -208,7 +219,7 @@ __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     const u32 d = X - Y + k.q;
     X = csub32(s, k.q);
     Y = csub32(shoup32(d, w, wp, k.q), k.q);
-  } else if constexpr (AR == 2) {
+  } else if constexpr (AR == 2 || AR == 4) {
     const u32 s = X + Y;
     const u32 d = X - Y + k.q2;
     X = csub32(s, k.q2);
@@ -234,7 +245,7 @@ __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT
     const u32 d = X - Y + k.q;
     X = csub32(shoup32(s, s0, s1, k.q), k.q);
     Y = csub32(shoup32(d, w, wp, k.q), k.q);
-  } else if constexpr (AR == 2) {
+  } else if constexpr (AR == 2 || AR == 4) {
     const u32 s = X + Y;
     const u32 d = X - Y + k.q2;
     X = shoup32(s, s0, s1, k.q);
@@ -254,6 +265,7 @@ __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT
 template <int AR> __device__ __forceinline__ VT<AR> canon_fwd(VT<AR> v, const QKT<AR>& k) {
   if constexpr (AR == 3) return csub32(v, k.q);
   else if constexpr (AR == 2) return csub32(csub32(v, k.q2), k.q);
+  else if constexpr (AR == 4) return csub32(v - __umulhi(v, k.mu) * k.q, k.q);     // any 32-bit v: v - floor(v mu / 2^32) q in [0,2q)
   else {
     if constexpr (AR == 1) v = csubn(v, k.nq4);
     return csubn(csubn(v, k.nq2), k.nq);
@@ -261,7 +273,7 @@ template <int AR> __device__ __forceinline__ VT<AR> canon_fwd(VT<AR> v, const QK
 }
 template <int AR> __device__ __forceinline__ VT<AR> canon_inv(VT<AR> v, const QKT<AR>& k) {
   if constexpr (AR == 3) return v;
-  else if constexpr (AR == 2) return csub32(v, k.q);
+  else if constexpr (AR == 2 || AR == 4) return csub32(v, k.q);
   else {
     if constexpr (AR == 1) v = csubn(v, k.nq2);
     return csubn(v, k.nq);
@@ -276,7 +288,7 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR
 // inverse transform accepts
 template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, const ModCtx& mc, const QKT<AR>& k) {
   if constexpr (AR >= 2) {
-    const u64 x = (u64)a * b;                          // < q * 4q < 2^62 (AR = 2), q * 2q < 2^63 (AR = 3)
+    const u64 x = (u64)a * b;                          // < q * 4q < 2^62 (AR = 2), q * 2q < 2^63 (AR = 3), q * 2^32 < 2^59 (AR = 4)
     const u64 Q = __umul64hi(x, mc.mu);                // floor(x/q) or one less
     return csub32((u32)(x - Q * mc.q), k.q);           // [0,2q) -> [0,q)
   } else if constexpr (AR == 1) {
@@ -759,7 +771,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
-  const QKT<AR> qk(mod[t].q, std::bool_constant<(NT >= 64 || TU)>{});
+  const QKT<AR> qk(mod[t], std::bool_constant<(NT >= 64 || TU)>{});
   // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
   // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
   // stores are dropped by the hardware range check.

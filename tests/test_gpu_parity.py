@@ -181,7 +181,7 @@ def test_dropin_honours_caller_roots(gpu, cpuref):
 # ---------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("L", range(1, 15))
-@pytest.mark.parametrize("T,lower", [(1, 2 ** 60), (3, 2 ** 29), (2, 2 ** 61)])
+@pytest.mark.parametrize("T,lower", [(1, 2 ** 60), (3, 2 ** 29), (2, 2 ** 61), (2, 2 ** 16)])
 def test_pow2_all_sizes(gpu, cpuref, L, T, lower):
     m = 2 ** (L + 1)
     g = lm.good_qs(m, lower)
@@ -342,9 +342,10 @@ def test_extreme_values_and_moduli(gpu, cpuref):
 @pytest.mark.parametrize("m", [2 ** 5, 2 ** 10, 2 ** 12, 2 ** 14])
 def test_arithmetic_class_boundaries(gpu, cpuref, m):
     """The m = 2^k path picks its arithmetic per plan: 32-bit residues when every modulus is
-    below 2^30 (lazy ranges) or below 2^31 (tighter ranges), 64-bit lazy Shoup below 2^61,
-    exact above.  Moduli hugging each boundary, the
-    extreme residues, and tuples that mix classes (the widest class must win)."""
+    below 2^27 (no conditional subtraction in the forward transform: values grow to 29 q), below
+    2^30 (lazy ranges) or below 2^31 (tighter ranges), 64-bit lazy Shoup below 2^61, exact above.
+    Moduli hugging each boundary, the extreme residues, and tuples that mix classes (the widest
+    class must win)."""
     pps = lm.factor_pps(m)
 
     def last_good_below(bound):
@@ -353,6 +354,9 @@ def test_arithmetic_class_boundaries(gpu, cpuref, m):
             q -= m
         return q
 
+    q_27 = last_good_below(2 ** 27)            # largest modulus of the subtraction-free class
+    q_27h = lm.first_good_q(m, 2 ** 27)        # smallest modulus of the lazy 32-bit class
+    assert q_27 < 2 ** 27 < q_27h
     q_lo = last_good_below(2 ** 30)            # largest modulus of the lazy 32-bit class
     q_mid = lm.first_good_q(m, 2 ** 30)        # smallest modulus of the second 32-bit class
     q_31 = last_good_below(2 ** 31)            # largest 32-bit modulus
@@ -361,7 +365,8 @@ def test_arithmetic_class_boundaries(gpu, cpuref, m):
     q_top = lm.first_good_q(m, 2 ** 61)        # smallest exact-class modulus
     assert q_lo < 2 ** 30 < q_mid < q_31 < 2 ** 31 < q_31h and q_hi < 2 ** 61 < q_top
     rng = np.random.default_rng(m)
-    for qs in ([q_lo], [q_mid], [q_31], [q_31h], [q_hi], [q_top], [q_lo, 12289 if m <= 4096 else 65537],
+    for qs in ([q_27], [q_27h], [q_27, 12289 if m <= 4096 else 65537], [q_27, q_27h],
+               [q_lo], [q_mid], [q_31], [q_31h], [q_hi], [q_top], [q_lo, 12289 if m <= 4096 else 65537],
                [q_lo, q_mid], [q_31, q_lo, q_mid], [q_31, q_31h], [q_mid, q_hi, q_lo], [q_top, q_lo]):
         P, R = gpu.Plan(pps, qs), Params(pps, qs)
         y, z = R.random(rng, 3), R.random(rng, 3)
