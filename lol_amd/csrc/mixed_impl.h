@@ -1,0 +1,385 @@
+// lol_amd/csrc/mixed_impl.h — device templates of the mixed-radix path (instantiated once per
+// arithmetic class in mixed_cls{0,1,2,3}.hip so the classes compile in parallel; dispatcher in mixed.hip):
+// the mixed-radix (any m with every prime <= 13, n <= 8192) path:
+// vector-per-thread interpreter of the plan's stage program, and the FUSED mixed-radix
+// poly-mul c = crtInv(crt a * crt b) in one launch.
+//
+// What the reference does per prime power with one sweep over memory per stage
+// (crt.cpp:459-538 through tensor.h:76-95; dense p-point forms crt.cpp:226-245,324-345,433-456;
+// L/G forms l.cpp:28-98, g.cpp:16-123) runs here with one polynomial component per workgroup
+// resident in LDS: every stage (I (x) A_p (x) I_rts) is applied by threads that each own one
+// d-vector, read it from LDS once, apply A_p in registers and write it back in place.
+//
+// Against the first version of this kernel (k_generic_vec, round 1):
+//   * global loads are issued in one batch of up to 16 per thread (the per-element load loop
+//     put ONE load per wave in flight: ~11 serial HBM round trips per polynomial of m = 15015);
+//   * three arithmetic/storage classes chosen per plan on the host:
+//       CLS 0  any q < 2^62:  64-bit residues in LDS, 128-bit dot-product accumulators;
+//       CLS 1  every q < 2^32: 32-bit residues in LDS and registers (half the LDS traffic and
+//              footprint), 32x32 products accumulated in 128 bits;
+//       CLS 3  64-bit residues, every q odd: as CLS 0 with the constants pre-scaled by 2^64 and ONE
+//              Montgomery reduction per dot product (~30 instructions against ~70);
+//       CLS 2  every q odd with 13 (q-1)^2 < 2^64: the whole dot product accumulates in ONE 64-bit
+//              v_mad_u64_u32 chain and is reduced once by a 9-instruction 32-bit Montgomery step
+//              (constants pre-scaled by 2^32) — the reference's own domain (q < 2^31.5,
+//              types.h:79-84) up to q < 2^30.15;
+//   * the poly-mul is ONE launch: a-hat waits in registers (each thread keeps the coefficients
+//     it loaded) while b goes through the same LDS buffer; b's global loads are issued before
+//     a's stages and land under them; HBM sees a and b once in and c once out (round 1: four
+//     launches through a plan-owned temp, 9 slab passes).
+#pragma once
+#include "pow2_impl.h"     // buffer-descriptor loads/stores, fresh()
+
+namespace lolhip {
+
+#ifndef LOLHIP_MIXED_W2
+#define LOLHIP_MIXED_W2 8
+#endif
+// coefficients a thread loads/stores: ppw * n <= KMAX * blockDim, KMAX in {12, 16} picked by the launcher
+// (m = 15015: 5760 / 512 = 11.25 -> 12: a quarter fewer predicated load/store/convert slots than 16)
+
+template <int CLS> using MV = std::conditional_t<CLS == 0 || CLS == 3, u64, u32>;
+template <int CLS> constexpr bool wide() { return CLS == 0 || CLS == 3; }
+
+// x / v for x <= 8192 (every index here is below ppw * n <= 8192) from the plan's 2^40-scaled
+// reciprocal M = floor(2^40/v)+1: (M >> 8) + 1 is floor(2^32/v) + 1 or + 2, whose error times x
+// stays below 2^27, so ONE v_mul_hi_u32 is exact (the scalar part is wave-uniform SALU work)
+__device__ __forceinline__ int mdiv(int x, u64 M) {
+  return (M >> 40) ? x : (int)__umulhi((u32)x, (u32)(M >> 8) + 1u);      // M >> 40 is set only for v = 1
+}
+
+template <int CLS> __device__ __forceinline__ MV<CLS> m_add(MV<CLS> a, MV<CLS> b, u64 q) {
+  if constexpr (wide<CLS>()) return addmod(a, b, q);
+  else if constexpr (CLS == 2) { const u32 s = a + b; return min(s, s - (u32)q); }   // q < 2^30.2: the sum fits a word
+  else { const u64 s = (u64)a + b; return (u32)(s >= q ? s - q : s); }          // q may exceed 2^31: 33-bit sum
+}
+template <int CLS> __device__ __forceinline__ MV<CLS> m_sub(MV<CLS> a, MV<CLS> b, u64 q) {
+  if constexpr (wide<CLS>()) return submod(a, b, q);
+  else if constexpr (CLS == 2) { const u32 d = a - b; return min(d, d + (u32)q); }   // a < b: d wraps high, d + q is the residue
+  else return a >= b ? a - b : (u32)(a + (u32)q - b);
+}
+// x mod q for a 64-bit x: Barrett with mu = floor(2^64 / q)
+__device__ __forceinline__ u32 barrett64(u64 x, const ModCtx& mc) {
+  const u64 Q = __umul64hi(x, mc.mu);             // floor(x/q) or one less
+  u64 r = x - Q * mc.q;                            // [0, 2q)
+  if (r >= mc.q) r -= mc.q;
+  return (u32)r;
+}
+// Montgomery reduction of a 128-bit value T < 13 q^2 with q < 2^61 (so T / 2^64 < 13 q / 8):
+//   (T + ((T mod 2^64) * (-q^-1) mod 2^64) * q) / 2^64  =  T * 2^-64 mod q,  below 2.625 q < 2^63;
+// two conditional subtractions make it canonical.  ~25 instructions against ~70 for the exact
+// two-step 128-by-64 division; the 2^-64 is absorbed by constants pre-scaled on the host.
+__device__ __forceinline__ u64 redc128(unsigned __int128 T, const ModCtx& mc) {
+  const u64 lo = (u64)T, hi = (u64)(T >> 64);
+  const u64 m = lo * mc.nqinv;
+  u64 r = hi + __umul64hi(m, mc.q) + (lo != 0);      // lo + lo64(m q) = 0 mod 2^64: it carries iff lo != 0
+  r = csub(r, 2 * mc.q);
+  return csub(r, mc.q);
+}
+// 32-bit Montgomery reduction of T < 13 q^2 < 2^64 (class 2; q odd, q < 2^30.15):
+//   h = T >> 32 < 3.6 q fits a word; h >= 2q ? h - 2q : h changes T by a multiple of q and leaves h < 2q;
+//   m = (T mod 2^32) * (-q^-1) mod 2^32;  T + m q = 0 mod 2^32, and (T mod 2^32) + (m q mod 2^32)
+//   carries iff m != 0, so the carry folds into the high word of m q + (2^32 - 1): ONE v_mad_u64_u32;
+//   result h + ceil(m q / 2^32) < 3 q + 1 < 2^32 = T 2^-32 mod q, two min-subtractions to canonical.
+// 9 instructions against ~25 for a 64-bit Barrett step; the 2^-32 is absorbed by constants
+// pre-scaled on the host.
+__device__ __forceinline__ u32 redc64(u64 T, const ModCtx& mc) {
+  const u32 q = (u32)mc.q;
+  u32 h = (u32)(T >> 32);
+  h = min(h, h - 2 * q);
+  const u32 m = (u32)T * (u32)mc.nqinv;
+  u32 r = h + (u32)(((u64)m * q + 0xFFFFFFFFull) >> 32);
+  r = min(r, r - 2 * q);
+  return min(r, r - q);
+}
+// a * b mod q.  KPOOL: b comes from the constant pool (pre-scaled by 2^32 / 2^64 in classes 2 / 3);
+// otherwise b is a plain residue or small integer and those classes multiply exactly.
+template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(MV<CLS> a, u64 b, const ModCtx& mc) {
+  if constexpr (CLS == 3 && KPOOL) return redc128((unsigned __int128)a * b, mc);
+  else if constexpr (CLS == 2 && KPOOL) return redc64((u64)a * (u32)b, mc);
+  else if constexpr (wide<CLS>()) return mulmod(a, b, mc);
+  else return barrett64((u64)a * (u32)b, mc);
+}
+
+// one output of a dense stage: sum_c v[c] * row[c] mod q
+template <int CLS, int D>
+__device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const u64* __restrict__ row, const ModCtx& mc) {
+  static_assert(D <= 16, "16 products below 2^124 fit in 128 bits");
+  if constexpr (CLS == 2) {
+    u64 acc = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc += (u64)v[c] * (u32)row[c];      // one v_mad_u64_u32 per term; D (q-1)^2 < 2^64
+    return redc64(acc, mc);
+  } else {
+    unsigned __int128 acc = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      if constexpr (CLS == 1) acc += (unsigned __int128)((u64)v[c] * (u32)row[c]);
+      else acc += (unsigned __int128)v[c] * row[c];          // classes 0 and 3: 13 products below 2^124
+    }
+    if constexpr (CLS == 3) return redc128(acc, mc);
+    if (CLS == 1 && mc.q > 16) return (MV<CLS>)rem128((u64)(acc >> 64), (u64)acc, mc);   // high word < 16 < q: one division step
+    return (MV<CLS>)reduce128((u64)(acc >> 64), (u64)acc, mc);
+  }
+}
+
+// one d-vector of one stage, in place in LDS
+template <int CLS, int D>
+__device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__ buf, int vec, int n, u64 n_magic,
+                                          const u64* __restrict__ cst, const ModCtx& mc) {
+  using V = MV<CLS>;
+  const u64 q = mc.q;
+  const int rts = st.rts;
+  const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
+  const int x0 = blk * D * rts + r;
+  V* base = buf + x0;
+  V v[D], o[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
+  // vectors of odd length p only occur in DFT_p stages; the L and G maps act on p-1 elements
+  // (and small multipliers such as p-1-i are below q: the host sends moduli <= 16 elsewhere)
+  switch ((D & 1) ? (int)ST_DFTP : st.kind) {
+    case ST_DFTP:
+    case ST_CRTP:
+    case ST_CRTPINV: {
+      const u64* M = cst + st.mat_off;
+#pragma unroll
+      for (int i = 0; i < D; ++i) o[i] = m_dot<CLS, D>(v, M + i * D, mc);
+      break;
+    }
+    case ST_L: {                         // prefix sums (l.cpp:28-57)
+      V s = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) { s = m_add<CLS>(s, v[i], q); o[i] = s; }
+      break;
+    }
+    case ST_LINV: {                      // adjacent differences (l.cpp:67-98)
+      o[0] = v[0];
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = m_sub<CLS>(v[i], v[i - 1], q);
+      break;
+    }
+    case ST_GPOW: {                      // g.cpp:16-35
+      const V last = v[D - 1];
+      o[0] = m_add<CLS>(v[0], last, q);
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = m_sub<CLS>(m_add<CLS>(v[i], last, q), v[i - 1], q);
+      break;
+    }
+    case ST_GDEC: {                      // g.cpp:37-58
+      V s = v[0];
+#pragma unroll
+      for (int c = 0; c < D; ++c) s = m_add<CLS>(s, v[c], q);
+      o[0] = s;
+#pragma unroll
+      for (int i = 1; i < D; ++i) o[i] = m_sub<CLS>(v[i], v[i - 1], q);
+      break;
+    }
+    case ST_GINVPOW: {                   // g.cpp:60-90: (p-1-i) * sum_{c<=i} - (i+1) * sum_{c>i}
+      V tot = 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) tot = m_add<CLS>(tot, v[c], q);
+      V le = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        le = m_add<CLS>(le, v[i], q);
+        const V re = m_sub<CLS>(tot, le, q);
+        o[i] = m_sub<CLS>(m_mul<CLS, false>(le, (u64)(st.p - 1 - i), mc), m_mul<CLS, false>(re, (u64)(i + 1), mc), q);
+      }
+      break;
+    }
+    case ST_GINVDEC: {                   // g.cpp:92-123: sum_c (c+1) v_c - p * sum_{c>i} v_c
+      V s = 0, tot = 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        s = m_add<CLS>(s, m_mul<CLS, false>(v[c], (u64)(c + 1), mc), q);
+        tot = m_add<CLS>(tot, v[c], q);
+      }
+      const u64 pm = (u64)st.p;
+      V le = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        le = m_add<CLS>(le, v[i], q);
+        o[i] = m_sub<CLS>(s, m_mul<CLS, false>(m_sub<CLS>(tot, le, q), pm, mc), q);
+      }
+      break;
+    }
+    default:
+#pragma unroll
+      for (int i = 0; i < D; ++i) o[i] = v[i];
+  }
+  if (st.tw_off >= 0) {                  // the diagonal folded into this stage (crtTwiddle/dftTwiddle, mhat^-1, oddRad^-1)
+    const int pi = mdiv(x0, n_magic);
+    const int xi0 = x0 - pi * n;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
+      o[i] = m_mul<CLS>(o[i], cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod], mc);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) base[i * rts] = o[i];
+}
+
+// every stage of one program over the `tot` packed coefficients in buf; ends with a barrier
+template <int CLS>
+__device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, int n, u64 n_magic,
+                                           const Stage* __restrict__ stages, int nstages,
+                                           const u64* __restrict__ cst, const ModCtx& mc) {
+  for (int s = 0; s < nstages; ++s) {
+    const Stage st = stages[s];
+    if (st.kind == ST_DIAG || st.kind == ST_SCALE) {
+      for (int x = threadIdx.x; x < tot; x += blockDim.x) {
+        const int pi = mdiv(x, n_magic);
+        const int xd = mdiv(x - pi * n, st.m_twdiv);
+        buf[x] = m_mul<CLS>(buf[x], cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod], mc);
+      }
+    } else {
+      const int nvec = mdiv(tot, st.m_d);           // tot / d: exact, tot < 2^20
+      for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
+        switch (st.d) {
+          case 2: stage_vec<CLS, 2>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 3: stage_vec<CLS, 3>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 4: stage_vec<CLS, 4>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 5: stage_vec<CLS, 5>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 6: stage_vec<CLS, 6>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 7: stage_vec<CLS, 7>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 10: stage_vec<CLS, 10>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 11: stage_vec<CLS, 11>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 12: stage_vec<CLS, 12>(st, buf, vec, n, n_magic, cst, mc); break;
+          case 13: stage_vec<CLS, 13>(st, buf, vec, n, n_magic, cst, mc); break;
+          default: break;   // excluded on the host (mixed_ok)
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
+  if constexpr (wide<CLS>()) return canon_in(x, q);
+  else return (u32)x + ((u32)q & (u32)(x >> 63));       // (-q, q) -> [0, q), q < 2^32
+}
+
+// MODE 0: y = program(a).  MODE 2: y = crtInv(crt(a) * crt(b)).
+// (Tables are separate __restrict__ parameters, not members of a struct: only then can the
+// compiler prove them unclobbered by the stores of earlier items and fetch matrix rows with
+// scalar loads — as struct members they became per-lane vector loads, 338 VGPRs of them at p = 13.)
+// Occupancy: a 46 KiB (23 KiB in the 32-bit classes) polynomial leaves LDS room for 3-6 workgroups
+// per CU; the single-program form of the 32-bit classes fits 80 VGPRs (6 waves/SIMD); the fused
+// poly-mul keeps a-hat and b's loads live and gets 128 (4 waves/SIMD), as does the 64-bit class
+// (at 80 it spills: measured slower).
+template <int CLS, int MODE, int KMAX>
+__global__ void __launch_bounds__(512, (MODE == 0 && CLS == 2) ? LOLHIP_MIXED_W2 : (MODE == 0 && CLS == 1) ? 6 : 4)
+k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int ppw, i64 ngroups,
+        const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
+        const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod) {
+  using V = MV<CLS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  V* buf = reinterpret_cast<V*>(smem);
+  const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
+  const i64 items = ngroups * T;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  for (i64 item = blockIdx.x; item < items; item += gridDim.x) {
+    const i64 g = item / T;
+    const int t = (int)(item % T);
+    const i64 b0 = g * ppw;
+    const int np = (int)((B - b0) < ppw ? (B - b0) : ppw);
+    const int tot = np * n;
+    const ModCtx mc = mod[t];
+    const u64* cst = consts + (size_t)t * cpc;
+    // Global memory through buffer descriptors over this group's window: one 32-bit lane offset
+    // plus a wave-uniform step per batch entry (no 64-bit addresses in VGPRs), and the range
+    // check does the x < tot predicate: loads past the window return 0, stores are dropped.
+    const size_t gbase = (size_t)b0 * n * T + (size_t)t;       // element x of this group lives at gbase + x * T
+    const u32 wbytes = ((u32)(tot - 1) * (u32)T + 1u) * 8u;    // <= 8192 * 64 * 8
+    const u32 step = (u32)nthr * (u32)T * 8u;
+    const rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_in + gbase), 0, wbytes, 0x00020000);
+    const rsrc_t wy = __builtin_amdgcn_make_buffer_rsrc((void*)(y_out + gbase), 0, wbytes, 0x00020000);
+    auto goff = [&]() -> u32 { return (u32)fresh(tid) * (u32)T * 8u; };
+    auto load16 = [&](u64 (&r)[KMAX], rsrc_t w) {
+      const u32 o = goff();
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) r[k] = (k * nthr < tot) ? load_u64(w, o, (u32)k * step) : 0;      // uniform skip of empty batches
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto to_lds = [&](const u64 (&r)[KMAX]) {
+      const int x0 = fresh(tid);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = from_raw<CLS>((i64)r[k], mc.q); }
+    };
+    auto store16 = [&]() {
+      const u32 o = goff();
+      const int x0 = fresh(tid);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (k * nthr < tot) store_u64(wy, o, (u32)k * step, (u64)buf[x < tot ? x : 0]); }
+    };
+
+    u64 ra[KMAX];
+    load16(ra, wa);
+    if constexpr (MODE == 0) {
+      to_lds(ra);
+      __syncthreads();
+      run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      store16();
+    } else {
+      const bool square = (a_in == b_in);
+      to_lds(ra);
+      // b's loads go out now and land under a's stages (holding them back to fit a third
+      // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
+      if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
+      __syncthreads();
+      run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      V ah[KMAX];                        // a-hat: every thread keeps the positions it owns
+      {
+        const int x0 = fresh(tid);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; ah[k] = x < tot ? buf[x] : 0; }
+      }
+      if (!square) {
+        __syncthreads();                 // every a-hat coefficient is in registers before b overwrites the buffer
+        to_lds(ra);
+        __syncthreads();
+        run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      }
+      {
+        const int x0 = fresh(tid);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
+      }
+      __syncthreads();
+      run_stages<CLS>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
+      store16();
+    }
+    __syncthreads();                     // the buffer is reused by the next item
+  }
+}
+
+template <int CLS, int MODE>
+hipError_t launch_cls(const MixedLaunch& a) {
+  using V = MV<CLS>;
+  // pack small polynomials up to ~2048 coefficients per workgroup
+  int ppw = 1;
+  while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
+  const i64 ngroups = (a.B + ppw - 1) / ppw;
+  const size_t coeffs = (size_t)ppw * a.n;
+  const size_t lds_bytes = coeffs * sizeof(V);
+  const int threads = coeffs > 4096 ? 512 : (coeffs > 2048 ? 256 : 128);     // coeffs <= 16 * threads
+  i64 grid = ngroups * a.T;
+  if (grid > 65536) grid = 65536;
+  const size_t per_thread = (coeffs + threads - 1) / threads;
+#define LOLHIP_MIXED_LAUNCH(K)                                                                                         \
+  hipLaunchKernelGGL((k_mixed<CLS, MODE, K>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.a, a.b, \
+                     a.B, a.T, (int)a.n, ppw, ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.cpc, a.mod)
+  if (per_thread <= 12) LOLHIP_MIXED_LAUNCH(12);
+  else LOLHIP_MIXED_LAUNCH(16);
+#undef LOLHIP_MIXED_LAUNCH
+  return hipGetLastError();
+}
+
+template <int CLS>
+hipError_t launch_mixed_cls(const MixedLaunch& a) {
+  return a.fused ? launch_cls<CLS, 2>(a) : launch_cls<CLS, 0>(a);
+}
+
+}  // namespace lolhip

@@ -3,7 +3,7 @@
 namespace lolhip {
 template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
 }  // namespace lolhip
-#ifdef LOLHIP_STAMPS
+#if defined(LOLHIP_STAMPS) && LOLHIP_STAMPS == 1      // diagnostic build only (make ... CXXFLAGS+=-DLOLHIP_STAMPS=1): phase stamps of THIS class
 extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(lolhip::g_stamp_buf), &dev, sizeof(dev));
 }

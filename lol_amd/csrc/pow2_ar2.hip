@@ -3,3 +3,8 @@
 namespace lolhip {
 template hipError_t launch_pow2_ar<2>(const Pow2Launch&, int);
 }  // namespace lolhip
+#if defined(LOLHIP_STAMPS) && LOLHIP_STAMPS == 2      // diagnostic build only (make ... CXXFLAGS+=-DLOLHIP_STAMPS=2): phase stamps of THIS class
+extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lolhip::g_stamp_buf), &dev, sizeof(dev));
+}
+#endif
