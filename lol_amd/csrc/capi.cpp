@@ -532,13 +532,13 @@ int64_t lolhip_ext_table(const lolhip_ext* x, int which, int32_t* out, int64_t l
 }
 
 static int ext_gather(const lolhip_ext* x, void* stream, int64_t* out, const int64_t* in, int64_t B,
-                      const int32_t* idx, bool to_hi) {
+                      const int32_t* idx, bool to_hi, bool replicating = false) {
   if (!x) return LOLHIP_ERR_INVALID;
   if (!idx) return LOLHIP_ERR_NO_DEVICE;
   if (B < 0 || (B > 0 && (!out || !in))) return LOLHIP_ERR_INVALID;
   const ExtPlan& X = x->X;
   const i64 n_out = to_hi ? X.host.phi2 : X.host.phi, n_in = to_hi ? X.host.phi : X.host.phi2;
-  return launch_gather((hipStream_t)stream, out, in, idx, B, n_out, n_in, X.lo->T, X.lo->d_mod) == hipSuccess
+  return launch_gather((hipStream_t)stream, out, in, idx, B, n_out, n_in, X.lo->T, X.lo->d_mod, replicating) == hipSuccess
              ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 int lolhip_twace_powdec_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const int64_t* hi_in, int64_t B) {
@@ -634,7 +634,7 @@ int lolhip_embed_dec_batch(const lolhip_ext* x, void* s, int64_t* hi_out, const 
 }
 int lolhip_embed_crt_batch(const lolhip_ext* x, void* s, int64_t* hi_out, const int64_t* lo_in, int64_t B) {
   if (x && !(x->X.lo->has_crt && x->X.hi->has_crt)) return LOLHIP_ERR_NO_CRT;   // Extension.hs:81-85 demands crtInfo m'
-  return ext_gather(x, s, hi_out, lo_in, B, x ? x->X.d_embed_crt : nullptr, true);
+  return ext_gather(x, s, hi_out, lo_in, B, x ? x->X.d_embed_crt : nullptr, true, true);
 }
 int lolhip_twace_crt_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const int64_t* hi_in, int64_t B) {
   if (!x) return LOLHIP_ERR_INVALID;

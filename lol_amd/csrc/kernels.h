@@ -85,8 +85,9 @@ hipError_t launch_cplx(hipStream_t s, double* y, i64 B, i64 n, const Stage* stag
 hipError_t launch_gauss(hipStream_t s, double* y, i64 B, i64 n, const Stage* stages, int nstages, const double* rconsts);
 
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod);
+// replicating: every output has a source (embedCRT) — worth staging the source polynomial in LDS
 hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,
-                         int T, const ModCtx* mod);
+                         int T, const ModCtx* mod, bool replicating = false);
 hipError_t launch_twace_crt(hipStream_t s, i64* out, const i64* in, const int32_t* idx, const i64* tweak, i64 B,
                             i64 n_out, i64 n_in, int T, const ModCtx* mod);
 

@@ -438,86 +438,236 @@ hipError_t launch_generic(const GenericLaunch& a) {
 // streaming kernels
 // =============================================================================
 
+// ---- streaming kernels -------------------------------------------------------------------------
+// One tile of consecutive elements per workgroup; the few divisions (which polynomial, which
+// modulus) are done once per workgroup or in 32 bits — the first version divided 64-bit indices
+// three times per element and ran at 0.29-0.39 of peak on config 5's embed/twace.
+
 // a[i] = a[i] * b[i mod bperiod]  (bperiod = total length for mulRq, n*T for g vectors)
+constexpr int PW_K = 8;                     // elements per thread
 __global__ void __launch_bounds__(256)
 k_pointwise_mul(i64* __restrict__ a, const i64* __restrict__ b, i64 total, i64 bperiod, int T,
                 const ModCtx* __restrict__ mod) {
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const ModCtx mc = mod[i % T];
-    const u64 x = canon_in(a[i], mc.q), z = canon_in(b[i % bperiod], mc.q);
-    a[i] = (i64)mulmod(x, z, mc);
+  const i64 s0 = (i64)blockIdx.x * (256 * PW_K);          // wave-uniform
+  const bool flat = (bperiod >= total);
+  const u32 t_s = (u32)((u64)s0 % (u32)T);
+  const u32 r_s = flat ? 0u : (u32)((u64)s0 % (u64)bperiod);     // bperiod = n * T < 2^31 whenever it is not the whole array
+  const u32 per = (u32)bperiod;
+  u64 x[PW_K], z[PW_K];
+#pragma unroll
+  for (int k = 0; k < PW_K; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 i = s0 + l;
+    if (i < total) {
+      x[k] = (u64)a[i];
+      z[k] = (u64)b[flat ? i : (i64)((r_s + l) % per)];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PW_K; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 i = s0 + l;
+    if (i < total) {
+      const ModCtx mc = mod[T == 1 ? 0u : (t_s + l) % (u32)T];
+      a[i] = (i64)mulmod(canon_in((i64)x[k], mc.q), canon_in((i64)z[k], mc.q), mc);
+    }
   }
 }
 
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod) {
   if (total == 0) return hipSuccess;
-  i64 blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const i64 blocks = (total + 256 * PW_K - 1) / (256 * PW_K);
+  if (blocks > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_pointwise_mul, dim3((unsigned)blocks), dim3(256), 0, s, a, b, total, bperiod, T, mod);
   return hipGetLastError();
 }
 
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+// TW consecutive components of one coefficient (16-byte accesses when T is even and the slabs are aligned)
+template <int TW> struct Chunk { u64 v[TW]; };
+template <int TW> __device__ __forceinline__ Chunk<TW> load_chunk(const i64* p) {
+  Chunk<TW> c;
+  if constexpr (TW == 2) { const u64x2 w = *reinterpret_cast<const u64x2*>(p); c.v[0] = w.x; c.v[1] = w.y; }
+  else c.v[0] = (u64)*p;
+  return c;
+}
+template <int TW> __device__ __forceinline__ void store_chunk(i64* p, const Chunk<TW>& c) {
+  if constexpr (TW == 2) { u64x2 w; w.x = c.v[0]; w.y = c.v[1]; *reinterpret_cast<u64x2*>(p) = w; }
+  else *p = (i64)c.v[0];
+}
+// tile bookkeeping shared by the gather-type kernels: chunk c of polynomial b -> (coefficient i, first component t0)
+struct TileArgs { u32 tiles, cpt, cpt_magic; };     // cpt = T / TW chunks per coefficient; magic = floor(2^32/cpt)+1 (unused for cpt = 1)
+static TileArgs tile_args(i64 n_out, int T, int TW, int K) {
+  TileArgs t;
+  t.cpt = (u32)(T / TW);
+  t.cpt_magic = t.cpt > 1 ? (u32)((((u64)1 << 32) / t.cpt) + 1) : 0;
+  const u64 chunks = (u64)n_out * t.cpt;
+  t.tiles = (u32)((chunks + 256 * K - 1) / (256 * K));
+  return t;
+}
+static bool aligned16(const void* a, const void* b) { return (((uintptr_t)a | (uintptr_t)b) & 15) == 0; }
+
 // out[b][i][t] = +-in[b][idx[i]][t] or 0  (embedPow/Dec/CRT, twacePowDec; Extension.hs:54-101)
+constexpr int GA_K = 4;
+template <int TW>
 __global__ void __launch_bounds__(256)
-k_gather(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __restrict__ idx, i64 B, i64 n_out,
-         i64 n_in, int T, const ModCtx* __restrict__ mod) {
-  const i64 total = B * n_out * T;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const int t = (int)(g % T);
-    const i64 r = g / T;
-    const i64 i = r % n_out, b = r / n_out;
-    const int32_t e = idx[i];
-    i64 val = 0;
-    if (e >= 0) {
-      const u64 q = mod[t].q;
-      const u64 x = canon_in(in[(b * n_in + (e & (EMBED_NEG_FLAG_DEV - 1))) * T + t], q);
-      val = (i64)((e & EMBED_NEG_FLAG_DEV) ? (x == 0 ? 0 : q - x) : x);
+k_gather(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __restrict__ idx, u32 n_out, u32 n_in, int T,
+         const ModCtx* __restrict__ mod, TileArgs ta) {
+  const u32 b = blockIdx.x / ta.tiles, tile = blockIdx.x - b * ta.tiles;          // wave-uniform
+  const i64* src = in + (size_t)b * n_in * T;
+  i64* dst = out + (size_t)b * n_out * T;
+  const u32 nchunks = n_out * ta.cpt;
+  int32_t e[GA_K];
+  u32 t0[GA_K];
+  Chunk<TW> v[GA_K];
+#pragma unroll
+  for (int k = 0; k < GA_K; ++k) {
+    const u32 c = (tile * GA_K + k) * 256u + threadIdx.x;
+    const u32 i = ta.cpt == 1 ? c : __umulhi(c, ta.cpt_magic);
+    t0[k] = (c - i * ta.cpt) * TW;
+    e[k] = c < nchunks ? idx[i] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < GA_K; ++k) {
+    if (e[k] >= 0) v[k] = load_chunk<TW>(src + (size_t)(e[k] & (EMBED_NEG_FLAG_DEV - 1)) * T + t0[k]);
+    else for (int j = 0; j < TW; ++j) v[k].v[j] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < GA_K; ++k) {
+    const u32 c = (tile * GA_K + k) * 256u + threadIdx.x;
+    if (c >= nchunks) continue;
+    if (e[k] >= 0) {
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const u64 q = mod[t0[k] + j].q;
+        const u64 x = canon_in((i64)v[k].v[j], q);
+        v[k].v[j] = (e[k] & EMBED_NEG_FLAG_DEV) ? (x == 0 ? 0 : q - x) : x;
+      }
     }
-    out[g] = val;
+    store_chunk<TW>(dst + (size_t)c * TW, v[k]);
+  }
+}
+
+// The same for a REPLICATING gather whose source polynomial fits LDS (embedCRT, n_out >= 2 n_in; embedPow/Dec
+// write mostly zeros and are faster without the staging): the
+// source is read from HBM once, coalesced, and the scattered reads hit LDS instead of the vector
+// L1 (embedCRT 2048 -> 14336 replicates every coefficient 6 times: 0.47 of peak through L1, 0.54 through LDS).
+template <int TW>
+__global__ void __launch_bounds__(256)
+k_gather_lds(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __restrict__ idx, u32 n_out, u32 n_in, int T,
+             const ModCtx* __restrict__ mod, TileArgs ta, u32 split, u32 cps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  i64* sm = reinterpret_cast<i64*>(smem);
+  const u32 b = blockIdx.x / split, part = blockIdx.x - b * split;               // wave-uniform
+  const i64* src = in + (size_t)b * n_in * T;
+  i64* dst = out + (size_t)b * n_out * T;
+  const u32 nsrc = n_in * (u32)T;
+  for (u32 x = threadIdx.x * TW; x < nsrc; x += 256u * TW) store_chunk<TW>(sm + x, load_chunk<TW>(src + x));
+  __syncthreads();
+  const u32 nchunks = n_out * ta.cpt;
+  const u32 c_end = min(nchunks, (part + 1) * cps);
+  for (u32 c0 = part * cps; c0 < c_end; c0 += 256u * GA_K) {
+    int32_t e[GA_K];
+    u32 t0[GA_K];
+#pragma unroll
+    for (int k = 0; k < GA_K; ++k) {
+      const u32 c = c0 + (u32)k * 256u + threadIdx.x;
+      const u32 i = ta.cpt == 1 ? c : __umulhi(c, ta.cpt_magic);
+      t0[k] = (c - i * ta.cpt) * TW;
+      e[k] = c < c_end ? idx[i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < GA_K; ++k) {
+      const u32 c = c0 + (u32)k * 256u + threadIdx.x;
+      if (c >= c_end) continue;
+      Chunk<TW> v;
+      if (e[k] >= 0) {
+        v = load_chunk<TW>(sm + (size_t)(e[k] & (EMBED_NEG_FLAG_DEV - 1)) * T + t0[k]);
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+          const u64 q = mod[t0[k] + j].q;
+          const u64 x = canon_in((i64)v.v[j], q);
+          v.v[j] = (e[k] & EMBED_NEG_FLAG_DEV) ? (x == 0 ? 0 : q - x) : x;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TW; ++j) v.v[j] = 0;
+      }
+      store_chunk<TW>(dst + (size_t)c * TW, v);
+    }
   }
 }
 
 hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,
-                         int T, const ModCtx* mod) {
-  const i64 total = B * n_out * T;
-  if (total == 0) return hipSuccess;
-  i64 blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, B, n_out, n_in, T, mod);
+                         int T, const ModCtx* mod, bool replicating) {
+  if (B * n_out * T == 0) return hipSuccess;
+  const int TW = (T % 2 == 0 && aligned16(out, in)) ? 2 : 1;
+  const size_t src_bytes = (size_t)n_in * T * 8;
+  if (replicating && src_bytes <= 64 * 1024 && n_out >= 2 * n_in) {
+    const TileArgs ta = tile_args(n_out, T, TW, GA_K);
+    // one workgroup copies the source once: give it at least ~4 source sizes of output to write
+    const u64 nchunks = (u64)n_out * ta.cpt;
+    u64 cps = (u64)4 * n_in * ta.cpt;
+    cps = (cps + 256 * GA_K - 1) / (256 * GA_K) * (256 * GA_K);
+    if (cps > nchunks) cps = (nchunks + 256 * GA_K - 1) / (256 * GA_K) * (256 * GA_K);
+    const u32 split = (u32)((nchunks + cps - 1) / cps);
+    const i64 blocks = B * split;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    if (TW == 2) hipLaunchKernelGGL(k_gather_lds<2>, dim3((unsigned)blocks), dim3(256), src_bytes, s, out, in, idx, (u32)n_out, (u32)n_in, T, mod, ta, split, (u32)cps);
+    else hipLaunchKernelGGL(k_gather_lds<1>, dim3((unsigned)blocks), dim3(256), src_bytes, s, out, in, idx, (u32)n_out, (u32)n_in, T, mod, ta, split, (u32)cps);
+    return hipGetLastError();
+  }
+  const TileArgs ta = tile_args(n_out, T, TW, GA_K);
+  const i64 blocks = B * ta.tiles;
+  if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+  if (TW == 2) hipLaunchKernelGGL(k_gather<2>, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, (u32)n_out, (u32)n_in, T, mod, ta);
+  else hipLaunchKernelGGL(k_gather<1>, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, (u32)n_out, (u32)n_in, T, mod, ta);
   return hipGetLastError();
 }
 
 // twaceCRT (Extension.hs:110-129): out[b][i][t] = sum_{r<rel} tweak[e]*in[b][e][t], e = idx[i*rel + r]
+constexpr int TC_K = 2;
+template <int TW>
 __global__ void __launch_bounds__(256)
 k_twace_crt(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __restrict__ idx,
-            const i64* __restrict__ tweak, i64 B, i64 n_out, i64 n_in, int T, const ModCtx* __restrict__ mod) {
-  const i64 total = B * n_out * T;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  const int rel = (int)(n_in / n_out);
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const int t = (int)(g % T);
-    const i64 r = g / T;
-    const i64 i = r % n_out, b = r / n_out;
-    const ModCtx mc = mod[t];
-    u64 acc = 0;
-    for (int k = 0; k < rel; ++k) {
-      const i64 e = idx[i * rel + k];
-      const u64 x = canon_in(in[(b * n_in + e) * T + t], mc.q);
-      acc = addmod(acc, mulmod(x, (u64)tweak[e * T + t], mc), mc.q);
+            const i64* __restrict__ tweak, u32 n_out, u32 n_in, int T, const ModCtx* __restrict__ mod, TileArgs ta) {
+  const u32 b = blockIdx.x / ta.tiles, tile = blockIdx.x - b * ta.tiles;
+  const i64* src = in + (size_t)b * n_in * T;
+  i64* dst = out + (size_t)b * n_out * T;
+  const u32 nchunks = n_out * ta.cpt;
+  const u32 rel = n_in / n_out;
+#pragma unroll
+  for (int k = 0; k < TC_K; ++k) {
+    const u32 c = (tile * TC_K + k) * 256u + threadIdx.x;
+    if (c >= nchunks) continue;
+    const u32 i = ta.cpt == 1 ? c : __umulhi(c, ta.cpt_magic);
+    const u32 t0 = (c - i * ta.cpt) * TW;
+    ModCtx mc[TW];
+#pragma unroll
+    for (int j = 0; j < TW; ++j) mc[j] = mod[t0 + j];
+    Chunk<TW> acc;
+#pragma unroll
+    for (int j = 0; j < TW; ++j) acc.v[j] = 0;
+    const int32_t* ip = idx + (size_t)i * rel;
+    for (u32 r = 0; r < rel; ++r) {
+      const size_t eo = (size_t)ip[r] * T + t0;
+      const Chunk<TW> x = load_chunk<TW>(src + eo), w = load_chunk<TW>(tweak + eo);
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc.v[j] = addmod(acc.v[j], mulmod(canon_in((i64)x.v[j], mc[j].q), w.v[j], mc[j]), mc[j].q);
     }
-    out[g] = (i64)acc;
+    store_chunk<TW>(dst + (size_t)c * TW, acc);
   }
 }
 
 hipError_t launch_twace_crt(hipStream_t s, i64* out, const i64* in, const int32_t* idx, const i64* tweak, i64 B,
                             i64 n_out, i64 n_in, int T, const ModCtx* mod) {
-  const i64 total = B * n_out * T;
-  if (total == 0) return hipSuccess;
-  i64 blocks = (total + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(k_twace_crt, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, tweak, B, n_out, n_in, T, mod);
+  if (B * n_out * T == 0) return hipSuccess;
+  const int TW = (T % 2 == 0 && aligned16(out, in) && aligned16(tweak, tweak)) ? 2 : 1;
+  const TileArgs ta = tile_args(n_out, T, TW, TC_K);
+  const i64 blocks = B * ta.tiles;
+  if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+  if (TW == 2) hipLaunchKernelGGL(k_twace_crt<2>, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, tweak, (u32)n_out, (u32)n_in, T, mod, ta);
+  else hipLaunchKernelGGL(k_twace_crt<1>, dim3((unsigned)blocks), dim3(256), 0, s, out, in, idx, tweak, (u32)n_out, (u32)n_in, T, mod, ta);
   return hipGetLastError();
 }
 

@@ -20,10 +20,16 @@ namespace lolhip {
 
 typedef unsigned __int128 u128;
 
-static inline unsigned grid_for(i64 total) {
-  i64 blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  return (unsigned)(blocks < 1 ? 1 : blocks);
+// Every kernel here walks a flat element index g.  A workgroup owns one tile of 256 * EPT
+// consecutive elements; whatever has to be divided out of g (position inside the polynomial,
+// component) is divided once per workgroup in 64 bits and per element in 32 bits only.
+constexpr int EPT = 2;                       // elements per thread
+constexpr i64 TILE = 256 * EPT;
+static inline bool tiles_for(i64 total, unsigned* blocks) {
+  const i64 b = (total + TILE - 1) / TILE;
+  if (b > 0x7fffffff) return false;
+  *blocks = (unsigned)(b < 1 ? 1 : b);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -32,9 +38,15 @@ static inline unsigned grid_for(i64 total) {
 __global__ void __launch_bounds__(256)
 k_ctmul(const i64* c0, const i64* c1, const i64* d0, const i64* d1, i64* e0, i64* e1, i64* e2,
         const i64* __restrict__ gcrt, i64 total, u32 per, int T, const ModCtx* __restrict__ mod) {
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const u32 r = (u32)(g % per);
+  const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
+  const u32 r_s = (u32)((u64)s0 % per);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 g = s0 + l;
+    if (g >= total) continue;
+    u32 r = r_s + l;
+    if (r >= per) r %= per;
     const ModCtx mc = mod[r % (u32)T];
     const u64 gv = (u64)gcrt[r];
     const u64 a0 = canon_in(c0[g], mc.q), a1 = canon_in(c1[g], mc.q);
@@ -54,7 +66,9 @@ hipError_t launch_ctmul(hipStream_t s, const i64* c0, const i64* c1, const i64* 
                         i64* e2, const i64* gcrt, i64 B, i64 n, int T, const ModCtx* mod) {
   const i64 total = B * n * T;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ctmul, dim3(grid_for(total)), dim3(256), 0, s, c0, c1, d0, d1, e0, e1, e2, gcrt, total,
+  unsigned blocks;
+  if (!tiles_for(total, &blocks)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_ctmul, dim3(blocks), dim3(256), 0, s, c0, c1, d0, d1, e0, e1, e2, gcrt, total,
                      (u32)(n * T), T, mod);
   return hipGetLastError();
 }
@@ -82,11 +96,18 @@ k_decompose(const i64* __restrict__ c, i64* __restrict__ digits, i64 rows, Decom
             const ModCtx* __restrict__ mod) {
   const int T = p.T;
   const i64 total = rows * T;              // one thread per output column (row r, component s)
-  const i64 stride = (i64)gridDim.x * blockDim.x;
   const i64 shift = p.base / 2;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const i64 r = g / T;
-    const int s = (int)(g - r * T);
+  const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
+  const i64 row_s = s0 / T;
+  const u32 t_s = (u32)(s0 - row_s * T);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 g = s0 + l;
+    if (g >= total) continue;
+    const u32 dr = (t_s + l) / (u32)T;
+    const i64 r = row_s + dr;
+    const int s = (int)(t_s + l - dr * (u32)T);
     const ModCtx ms = mod[s];
     i64 j = 0;
     for (int t = 0; t < T; ++t) {
@@ -110,7 +131,9 @@ hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64
                             const ModCtx* mod) {
   const i64 rows = B * n;
   if (rows == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_decompose, dim3(grid_for(rows * p.T)), dim3(256), 0, s, c, digits, rows, p, mod);
+  unsigned blocks;
+  if (!tiles_for(rows * p.T, &blocks)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, s, c, digits, rows, p, mod);
   return hipGetLastError();
 }
 
@@ -121,9 +144,15 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_knapsack(const i64* __restrict__ xs, int L, const i64* __restrict__ hint, const i64* addend, i64* out, i64 total,
            u32 per, int T, const ModCtx* __restrict__ mod) {
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const u32 r = (u32)(g % per);
+  const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
+  const u32 r_s = (u32)((u64)s0 % per);
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const u32 l = (u32)e * 256u + threadIdx.x;
+    const i64 g = s0 + l;
+    if (g >= total) continue;
+    u32 r = r_s + l;
+    if (r >= per) r %= per;
     const ModCtx mc = mod[r % (u32)T];
     u128 acc[K];
 #pragma unroll
@@ -153,7 +182,9 @@ hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint,
                            i64 B, i64 n, int T, const ModCtx* mod) {
   const i64 total = B * n * T;
   if (total == 0) return hipSuccess;
-  const dim3 grid(grid_for(total)), block(256);
+  unsigned blocks;
+  if (!tiles_for(total, &blocks)) return hipErrorInvalidValue;
+  const dim3 grid(blocks), block(256);
   const u32 per = (u32)(n * T);
   switch (K) {
     case 1: hipLaunchKernelGGL(k_knapsack<1>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
@@ -171,11 +202,18 @@ __global__ void __launch_bounds__(256)
 k_rescale(const i64* __restrict__ c, i64* __restrict__ out, i64 rows, RescaleParams p, const ModCtx* __restrict__ mod) {
   const int To = p.T - 1;
   const i64 total = rows * To;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
   const u64 qa = mod[0].q;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const i64 r = g / To;
-    const int s = (int)(g - r * To) + 1;
+  const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
+  const i64 row_s = s0 / To;
+  const u32 t_s = (u32)(s0 - row_s * To);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 g = s0 + l;
+    if (g >= total) continue;
+    const u32 dr = (t_s + l) / (u32)To;
+    const i64 r = row_s + dr;
+    const int s = (int)(t_s + l - dr * (u32)To) + 1;
     const ModCtx ms = mod[s];
     const u64 a = canon_in(c[r * p.T], qa);
     const i64 z = (2 * a < qa) ? (i64)a : (i64)a - (i64)qa;      // lift a
@@ -188,7 +226,9 @@ hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, c
                           const ModCtx* mod) {
   const i64 rows = B * n;
   if (rows == 0 || p.T < 2) return hipSuccess;
-  hipLaunchKernelGGL(k_rescale, dim3(grid_for(rows * (p.T - 1))), dim3(256), 0, s, c, out, rows, p, mod);
+  unsigned blocks;
+  if (!tiles_for(rows * (p.T - 1), &blocks)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_rescale, dim3(blocks), dim3(256), 0, s, c, out, rows, p, mod);
   return hipGetLastError();
 }
 
@@ -202,13 +242,22 @@ k_coeffs(i64* __restrict__ out, const i64* __restrict__ in, const int32_t* __res
          int T, const ModCtx* __restrict__ mod) {
   const i64 slab = B * n_lo * T;                    // one output vector over the whole batch
   const i64 total = B * n_hi * T;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
   const u32 per = n_lo * (u32)T;
-  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const i64 i1 = g / slab;
-    const i64 w = g - i1 * slab;                    // position inside output vector i1: (b, i0, t)
-    const i64 b = w / per;
-    const u32 r = (u32)(w - b * per);
+  const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
+  const i64 i1_s = s0 / slab;
+  const i64 w_s = s0 - i1_s * slab;                 // position inside output vector i1: (b, i0, t)
+  const i64 b_s = w_s / per;
+  const u32 r_s = (u32)(w_s - b_s * per);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const u32 l = (u32)k * 256u + threadIdx.x;
+    const i64 g = s0 + l;
+    if (g >= total) continue;
+    u32 r = r_s + l;
+    const u32 db = r / per;
+    r -= db * per;
+    i64 b = b_s + db, i1 = i1_s;
+    while (b >= B) { b -= B; ++i1; }                // a tile may run into the next output vector
     const u32 i0 = r / (u32)T, t = r - i0 * (u32)T;
     const int32_t e = idx[i1 * n_lo + i0];
     out[g] = (i64)canon_in(in[(b * n_hi + e) * T + t], mod[t].q);
@@ -219,7 +268,9 @@ hipError_t launch_coeffs(hipStream_t s, i64* out, const i64* in, const int32_t* 
                          const ModCtx* mod) {
   const i64 total = B * n_hi * T;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_coeffs, dim3(grid_for(total)), dim3(256), 0, s, out, in, idx, B, (u32)n_lo, (u32)n_hi, T, mod);
+  unsigned blocks;
+  if (!tiles_for(total, &blocks)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_coeffs, dim3(blocks), dim3(256), 0, s, out, in, idx, B, (u32)n_lo, (u32)n_hi, T, mod);
   return hipGetLastError();
 }
 

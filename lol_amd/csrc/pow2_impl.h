@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -830,6 +829,8 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     LH_STAMP(9);
     const bool square = (a_in == b_in);
     if (!square) {
+      // (issuing these with a's loads and holding the 32 raw registers across a's transform
+      // was measured: no gain at q ~ 2^30, 7% slower in class 4 — 6 instead of 8 waves/SIMD)
       u64 raw[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) raw[e] = load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8);

@@ -286,6 +286,45 @@ def test_twace_embed_vs_oracle(gpu, cpuref, m, m2, q):
         assert np.array_equal(acc, hi)
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 4])
+def test_streaming_kernels_layouts(gpu, cpuref, T):
+    """mulRq / mulG*CRT / twace* / embed* on device slabs: every tupSize path (16-byte chunks for even T,
+    the magic-division path for odd T), slabs that are only 8-byte aligned, a batch that does not fill the
+    last tile, a source polynomial too large for the LDS-staged gather, and a g vector shorter than a tile."""
+    import torch
+    for m, m2, B in ((8, 56, 5), (64, 64 * 7 * 3, 3), (2 ** 13, 2 ** 13 * 3, 2), (3, 3, 4)):
+        a, b = lm.factor_pps(m), lm.factor_pps(m2)
+        qs, lo_q = [], 2 ** 20
+        for _ in range(T):
+            lo_q = lm.first_good_q(m2, lo_q); qs.append(lo_q)
+        Pl, Ph = gpu.Plan(a, qs), gpu.Plan(b, qs)
+        X = gpu.Ext(Pl, Ph)
+        Rl, Rh = Params(a, qs), Params(b, qs)
+        rng = np.random.default_rng(m2 + T)
+        lo, hi = Rl.random(rng, B), Rh.random(rng, B)
+
+        def dev(x, shift):                              # a device copy whose base address is 8 mod 16 when shift = 1
+            buf = torch.empty(x.size + 2, dtype=torch.int64, device="cuda")
+            off = (1 if (buf.data_ptr() % 16 == 0) else 0) if shift else (0 if (buf.data_ptr() % 16 == 0) else 1)
+            v = buf[off:off + x.size].view(x.shape)
+            v.copy_(torch.from_numpy(x))
+            return v
+        for shift in (0, 1):
+            dl, dh = dev(lo, shift), dev(hi, shift)
+            assert np.array_equal(X.embedPow(dl).cpu().numpy(), cpuref.embed_pow(Rl, Rh, lo)), (m, m2, shift)
+            assert np.array_equal(X.embedDec(dl).cpu().numpy(), cpuref.embed_dec(Rl, Rh, lo)), (m, m2, shift)
+            assert np.array_equal(X.embedCRT(dl).cpu().numpy(), cpuref.embed_crt(Rl, Rh, lo)), (m, m2, shift)
+            assert np.array_equal(X.twacePowDec(dh).cpu().numpy(), cpuref.twace_powdec(Rl, Rh, hi)), (m, m2, shift)
+            assert np.array_equal(X.twaceCRT(dh).cpu().numpy(), cpuref.twace_crt(Rl, Rh, hi)), (m, m2, shift)
+            out = dev(np.zeros_like(hi), shift)
+            X.embedCRT(dl, out=out)
+            assert np.array_equal(out.cpu().numpy(), cpuref.embed_crt(Rl, Rh, lo)), (m, m2, shift)
+            h2 = dev(Rh.random(rng, B), shift)
+            assert np.array_equal(Ph.mul(dh.clone(), h2).cpu().numpy(), cpuref.mul(Rh, hi, h2.cpu().numpy())), (m, m2, shift)
+            assert np.array_equal(Ph.mulGCRT(dh.clone()).cpu().numpy(), cpuref.crt(Rh, cpuref.gpow(Rh, cpuref.crtinv(Rh, hi)))), (m, m2, shift)
+            assert np.array_equal(Pl.mulGCRT(dl.clone()).cpu().numpy(), cpuref.crt(Rl, cpuref.gpow(Rl, cpuref.crtinv(Rl, lo)))), (m, m2, shift)   # TensorTests.hs:107-112
+
+
 # ---------------------------------------------------------------------------------------
 # edge cases
 # ---------------------------------------------------------------------------------------

@@ -92,6 +92,32 @@ def main():
     ms = timeit(lambda: L.lolhip_rescale_drop_batch(P._h, st, ptr(c), ptr(out), B))
     report("rescale_drop", f"m=2^15 T=4->3 B={B}", ms, B, B * P.n * 7 * 8)
 
+    streaming(gen)
+
+
+def streaming(gen):
+    """the HBM-bound Tensor members of SURVEY 8(a) a6, a12-a15: mulRq, mulGCRT, twace*/embed* (config 5's ring pair)"""
+    if "--no-streaming" in sys.argv:
+        return
+    q61 = lol_amd.good_q(2 ** 14, 2 ** 60)
+    for cfg, pps, qs, B in (("m=2^14 T=1 61-bit", [(2, 14)], [q61], 4096), ("m=2^11 T=2 q~2^20", [(2, 11)], [1017857, 1032193], 32768)):
+        P = lol_amd.Plan(pps, qs)
+        a, b = rnd(gen, qs, B, P.n), rnd(gen, qs, B, P.n)
+        slab = B * P.n * P.T * 8
+        report("mulRq", f"{cfg} B={B}", timeit(lambda: P.mul(a, b)), B, 3 * slab)
+        report("mulGCRT", f"{cfg} B={B}", timeit(lambda: P.mulGCRT(a)), B, 2 * slab)
+    qs, B = [1017857, 1032193], 8192          # both are 1 mod 14336
+    lo, hi = lol_amd.Plan([(2, 11)], qs), lol_amd.Plan([(2, 11), (7, 1)], qs)
+    E = lol_amd.Ext(lo, hi)
+    x_lo, x_hi = rnd(gen, qs, B, lo.n), rnd(gen, qs, B, hi.n)
+    o_lo, o_hi = torch.empty_like(x_lo), torch.empty_like(x_hi)
+    byts = B * (lo.n + hi.n) * 2 * 8
+    cfg = f"2048 -> 14336 T=2 B={B}"
+    for name, fn in (("embedPow", lambda: E.embedPow(x_lo, out=o_hi)), ("embedDec", lambda: E.embedDec(x_lo, out=o_hi)),
+                     ("embedCRT", lambda: E.embedCRT(x_lo, out=o_hi)), ("twacePowDec", lambda: E.twacePowDec(x_hi, out=o_lo)),
+                     ("twaceCRT", lambda: E.twaceCRT(x_hi, out=o_lo))):
+        report(name, cfg, timeit(fn), B, byts)
+
 
 if __name__ == "__main__":
     main()
