@@ -451,7 +451,7 @@ int plan_upload(Plan& P) {
     P.pow2.arith32 = 4;
     for (u64 q : P.qs) { if (q >= (1ull << 27)) P.pow2.arith32 = 2; }
     for (u64 q : P.qs) { if (q >= (1ull << 30)) P.pow2.arith32 = 3; }
-    for (u64 q : P.qs) { if (q >= (1ull << 31)) P.pow2.arith32 = 0; }
+    for (u64 q : P.qs) { if (q >= (1ull << 31) || !(q & 1)) P.pow2.arith32 = 0; }     // the 32-bit classes' pointwise product is a Montgomery step: odd q
     if (P.pow2.arith32) {   // 32-bit Shoup pairs: wp = floor(w * 2^32 / q)
       std::vector<uint32_t> f32(fwd.size()), i32(inv.size()), s32(sc.size());
       for (int t = 0; t < T; ++t) {

@@ -170,8 +170,10 @@ struct QK {
 };
 struct QK32 {
   u32 q, q2, mu;       // mu = floor(2^32 / q): one-step Barrett of the wide lazy range of AR = 4
+  u32 r, rp, nqinv;    // Shoup pair of 2^32 mod q and -q^-1 mod 2^32: the fused poly-mul's Montgomery pointwise product
   template <bool UNIFORM>
-  __device__ __forceinline__ QK32(const ModCtx& mc, std::bool_constant<UNIFORM>) : q((u32)mc.q), q2(2 * (u32)mc.q), mu((u32)(mc.mu >> 32)) {}
+  __device__ __forceinline__ QK32(const ModCtx& mc, std::bool_constant<UNIFORM>)
+      : q((u32)mc.q), q2(2 * (u32)mc.q), mu((u32)(mc.mu >> 32)), r(mc.r32), rp(mc.r32p), nqinv((u32)mc.nqinv) {}
 };
 template <int AR> using QKT = std::conditional_t<AR >= 2, QK32, QK>;
 
@@ -283,13 +285,25 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR
   if constexpr (AR >= 2) return (u32)x + (k.q & (u32)(x >> 63));
   else return canon_in(x, k.q);
 }
-// pointwise product of a canonical a-hat and a lazy b-hat (forward range), any range the
+// the operand of the fused poly-mul that waits in registers: canonical in the 64-bit classes; in the
+// 32-bit ones canonical AND multiplied by 2^32 (one Shoup product, valid for any lazy 32-bit value),
+// so that the pointwise product below is a bare Montgomery reduction
+template <int AR> __device__ __forceinline__ VT<AR> park_fwd(VT<AR> v, const QKT<AR>& k) {
+  if constexpr (AR >= 2) return csub32(shoup32(v, k.r, k.rp, k.q), k.q);
+  else return canon_fwd<AR>(v, k);
+}
+// pointwise product of a parked a-hat and a lazy b-hat (forward range), any range the
 // inverse transform accepts
 template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, const ModCtx& mc, const QKT<AR>& k) {
   if constexpr (AR >= 2) {
-    const u64 x = (u64)a * b;                          // < q * 4q < 2^62 (AR = 2), q * 2q < 2^63 (AR = 3), q * 2^32 < 2^59 (AR = 4)
-    const u64 Q = __umul64hi(x, mc.mu);                // floor(x/q) or one less
-    return csub32((u32)(x - Q * mc.q), k.q);           // [0,2q) -> [0,q)
+    // a = a-hat 2^32 mod q < q; b < 4q (AR = 2), 2q (AR = 3), 29q (AR = 4): x = a b < q 2^32.
+    // REDC: m = x (-q^-1) mod 2^32; (x + m q) / 2^32 = a-hat b-hat mod q, below 2q; 4 instructions
+    // (the 64-bit Barrett step this replaces: ~16)
+    const u64 x = (u64)a * b;
+    const u32 m = (u32)x * k.nqinv;
+    const u32 t = (u32)((x + (u64)m * k.q) >> 32);
+    if constexpr (AR == 3) return csub32(t, k.q);      // this class's inverse takes canonical values
+    else return t;                                     // [0,2q): the inverse's lazy range
   } else if constexpr (AR == 1) {
     return mulmod(a, b, mc);                           // a < q, b < 8q: a*b < q * 2^64
   } else {
@@ -825,7 +839,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     // both operands are fully read before the first store to c.
     V va[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) va[e] = canon_fwd<AR>(v[e], qk);
+    for (int e = 0; e < E; ++e) va[e] = park_fwd<AR>(v[e], qk);
     LH_STAMP(9);
     const bool square = (a_in == b_in);
     if (!square) {
@@ -845,7 +859,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     LH_STAMP(19);
     const ModCtx mc = mod[t];     // re-read here: keeping it live across the transforms costs registers
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = pmul<AR>(va[e], square ? va[e] : v[e], mc, qk);
+    for (int e = 0; e < E; ++e) v[e] = pmul<AR>(va[e], (AR < 2 && square) ? va[e] : v[e], mc, qk);   // squaring: v still holds a-hat (lazy)
     LH_STAMP(22);
   }
   if constexpr (MODE == 2 && L >= TWL_MIN_L) {

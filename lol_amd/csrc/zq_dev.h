@@ -35,9 +35,11 @@ struct ModCtx {
   u64 d;   // q << s, top bit set
   u64 v;   // floor((2^128-1)/d) - 2^64
   u32 s;   // normalisation shift (>= 2 because q < 2^62)
-  u32 pad;
+  u32 r32; // 2^32 mod q when q < 2^32 (else 0): into 32-bit Montgomery form with one Shoup product
   u64 mu;  // floor(2^64 / q) (Barrett constant of the 32-bit path)
-  u64 nqinv;  // -q^-1 mod 2^64 for odd q (Montgomery reduction in the mixed-radix 64-bit class), else 0
+  u64 nqinv;  // -q^-1 mod 2^64 for odd q (Montgomery reductions), else 0
+  u32 r32p;   // floor(r32 * 2^32 / q)
+  u32 pad;
 };
 
 // Shoup pair: w and floor(w * 2^64 / q)
@@ -51,6 +53,11 @@ inline ModCtx make_modctx(u64 q) {
   c.d = q << c.s;
   c.v = (u64)((~(unsigned __int128)0) / c.d - ((unsigned __int128)1 << 64));
   c.pad = 0;
+  c.r32 = c.r32p = 0;
+  if (q < ((u64)1 << 32)) {
+    c.r32 = (u32)((((u64)1) << 32) % q);
+    c.r32p = (u32)((((u64)c.r32) << 32) / q);
+  }
   c.mu = (u64)((((unsigned __int128)1) << 64) / q);
   c.nqinv = 0;
   if (q & 1) {                       // Newton iteration: x <- x (2 - q x), doubling the correct low bits
