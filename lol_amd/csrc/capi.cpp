@@ -83,6 +83,12 @@ bool use_mixed(const Plan& P, const StageProgram& sp) {
   return !scalar_only && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
 }
 
+// m = 2^e * odd in one launch of the vector interpreter (plan.h: prog_crt_fused)
+bool use_fused2(const Plan& P) {
+  static const bool off = getenv("LOLHIP_NO_FUSED2") != nullptr;                     // A/B switch
+  return !off && P.fused2 && use_mixed(P, P.prog_crt_fused) && use_mixed(P, P.prog_crtinv_fused);
+}
+
 // y = program(src or y) over B polynomials
 int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, int64_t B, const int64_t* src = nullptr) {
   if (use_mixed(P, sp)) {
@@ -131,6 +137,11 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
 // stage program alone
 int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
   if (P.is_pow2) return run_pow2(P, inverse ? 1 : 0, s, y, nullptr, nullptr, B);
+  // a lone transform of m = 2^e * odd: one launch of the interpreter, except with 64-bit residues and
+  // e >= 5, where the m = 2^k kernels' cheaper butterflies outweigh the second pass over the slab
+  // (measured at 58 bits: m = 11648 0.62 vs 0.55 ms, m = 14336 0.65 vs 0.52 ms; at 26 bits fused wins everywhere)
+  const bool wide = P.mixed_cls == 0 || P.mixed_cls == 3;
+  if (use_fused2(P) && !(wide && P.pow2_part)) return run_prog(P, inverse ? P.prog_crtinv_fused : P.prog_crt_fused, s, y, B);
   if (P.pow2_part && !getenv("LOLHIP_NO_POW2_PART")) {
     const int64_t blocks = B * (P.n >> P.pow2.L);       // contiguous 2^(e-1)-coefficient blocks
     if (!inverse) {
@@ -227,13 +238,16 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   hipStream_t s = (hipStream_t)stream;
   if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
   static const bool unfused = getenv("LOLHIP_POLYMUL_UNFUSED") != nullptr;          // A/B switch
-  const bool split2 = P.pow2_part && !getenv("LOLHIP_NO_POW2_PART");   // the 2-power factor has its own kernels
-  if (!unfused && !split2 && use_mixed(P, P.prog_crt) && use_mixed(P, P.prog_crtinv)) {
+  const bool fused2 = use_fused2(P);
+  const bool split2 = !fused2 && P.pow2_part && !getenv("LOLHIP_NO_POW2_PART");   // the 2-power factor has its own kernels
+  if (!unfused && !split2 && (fused2 || (use_mixed(P, P.prog_crt) && use_mixed(P, P.prog_crtinv)))) {
     // one launch: a-hat in registers, b through the same LDS buffer, 3 slab passes (mixed.hip)
+    const StageProgram& pf = fused2 ? P.prog_crt_fused : P.prog_crt;
+    const StageProgram& pi = fused2 ? P.prog_crtinv_fused : P.prog_crtinv;
     MixedLaunch m;
     m.stream = s; m.y = c; m.a = a; m.b = b; m.B = B; m.T = P.T; m.n = P.n;
-    m.st_a = P.prog_crt.d_stages; m.n_a = P.prog_crt.nstages;
-    m.st_b = P.prog_crtinv.d_stages; m.n_b = P.prog_crtinv.nstages;
+    m.st_a = pf.d_stages; m.n_a = pf.nstages;
+    m.st_b = pi.d_stages; m.n_b = pi.nstages;
     m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true;
     return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }

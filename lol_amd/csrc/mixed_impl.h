@@ -92,11 +92,25 @@ __device__ __forceinline__ u32 redc64(u64 T, const ModCtx& mc) {
   r = min(r, r - 2 * q);
   return min(r, r - q);
 }
-// a * b mod q.  KPOOL: b comes from the constant pool (pre-scaled by 2^32 / 2^64 in classes 2 / 3);
-// otherwise b is a plain residue or small integer and those classes multiply exactly.
+// The same reductions for ONE product T = a b < q^2 of canonical residues (twiddle diagonals, the 2-power
+// tiles): the high word is already small (class 2: T / 2^32 < q / 3.6; class 3: T / 2^64 < q / 8), so the
+// result is below 2q without the pre-subtractions and one conditional subtraction makes it canonical.
+__device__ __forceinline__ u64 redc128_1(unsigned __int128 T, const ModCtx& mc) {
+  const u64 lo = (u64)T, hi = (u64)(T >> 64);
+  const u64 m = lo * mc.nqinv;
+  return csub(hi + __umul64hi(m, mc.q) + (lo != 0), mc.q);
+}
+__device__ __forceinline__ u32 redc64_1(u64 T, const ModCtx& mc) {
+  const u32 q = (u32)mc.q;
+  const u32 m = (u32)T * (u32)mc.nqinv;
+  const u32 r = (u32)(T >> 32) + (u32)(((u64)m * q + 0xFFFFFFFFull) >> 32);
+  return min(r, r - q);
+}
+// a * b mod q for canonical a.  KPOOL: b comes from the constant pool (pre-scaled by 2^32 / 2^64 in
+// classes 2 / 3); otherwise b is a plain residue or small integer and those classes multiply exactly.
 template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(MV<CLS> a, u64 b, const ModCtx& mc) {
-  if constexpr (CLS == 3 && KPOOL) return redc128((unsigned __int128)a * b, mc);
-  else if constexpr (CLS == 2 && KPOOL) return redc64((u64)a * (u32)b, mc);
+  if constexpr (CLS == 3 && KPOOL) return redc128_1((unsigned __int128)a * b, mc);
+  else if constexpr (CLS == 2 && KPOOL) return redc64_1((u64)a * (u32)b, mc);
   else if constexpr (wide<CLS>()) return mulmod(a, b, mc);
   else return barrett64((u64)a * (u32)b, mc);
 }
@@ -221,6 +235,92 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
   for (int i = 0; i < D; ++i) base[i * rts] = o[i];
 }
 
+// ST_POW2F / ST_POW2I: K levels of the 2-power factor on one 2^K-element register tile (plan.h).
+// Element j of tile (high, low) sits at (high << (sh + K) | low) + j * rts, rts = 2^sh = 2^(s_lo - 1);
+// the butterfly of level s_lo + l on elements j, j | 2^l uses table entry (rts << l) + low + (j mod 2^l) * rts.
+// Canonical residues in and out of every butterfly (m_mul reduces fully), so the tiles compose with the
+// odd primes' stages in any order.
+template <int CLS, int K, bool INV>
+__device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict__ buf, int tile,
+                                           const u64* __restrict__ cst, const ModCtx& mc) {
+  using V = MV<CLS>;
+  constexpr int NE = 1 << K;
+  const u64 q = mc.q;
+  const int rts = st.rts, sh = st.p - 1;
+  const int low = tile & (rts - 1), high = tile >> sh;
+  V* base = buf + ((high << (sh + K)) | low);
+  V v[NE];
+  if (rts == 1) {                      // contiguous tile: 16-byte LDS accesses
+    constexpr int PER = 16 / (int)sizeof(V);
+    typedef V VV __attribute__((ext_vector_type(PER)));
+    if constexpr (NE >= PER) {
+#pragma unroll
+      for (int c = 0; c < NE / PER; ++c) {
+        const VV w = reinterpret_cast<const VV*>(base)[c];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[c * PER + k] = w[k];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) v[j] = base[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) v[j] = base[j * rts];
+  }
+  const u64* tw = cst + st.tw_off + low;
+  if constexpr (!INV) {
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+      const int half = rts << l;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (j & (1 << l)) continue;
+        const V t = m_mul<CLS>(v[j | (1 << l)], tw[half + (j & ((1 << l) - 1)) * rts], mc);
+        const V x = v[j];
+        v[j] = m_add<CLS>(x, t, q);
+        v[j | (1 << l)] = m_sub<CLS>(x, t, q);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int l = K - 1; l >= 0; --l) {
+      const int half = rts << l;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (j & (1 << l)) continue;
+        const V x = v[j], y = v[j | (1 << l)];
+        v[j] = m_add<CLS>(x, y, q);
+        v[j | (1 << l)] = m_mul<CLS>(m_sub<CLS>(x, y, q), tw[half + (j & ((1 << l) - 1)) * rts], mc);
+      }
+    }
+    if (st.mat_off >= 0) {             // this tile holds level 1: its X outputs take mhat^-1 here (the Y outputs through the table)
+      const u64 mh = cst[st.mat_off];
+#pragma unroll
+      for (int j = 0; j < NE; j += 2) v[j] = m_mul<CLS>(v[j], mh, mc);
+    }
+  }
+  if (rts == 1) {
+    constexpr int PER = 16 / (int)sizeof(V);
+    typedef V VV __attribute__((ext_vector_type(PER)));
+    if constexpr (NE >= PER) {
+#pragma unroll
+      for (int c = 0; c < NE / PER; ++c) {
+        VV w;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) w[k] = v[c * PER + k];
+        reinterpret_cast<VV*>(base)[c] = w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) base[j] = v[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) base[j * rts] = v[j];
+  }
+}
+
 // every stage of one program over the `tot` packed coefficients in buf; ends with a barrier
 template <int CLS>
 __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, int n, u64 n_magic,
@@ -233,6 +333,22 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
         const int pi = mdiv(x, n_magic);
         const int xd = mdiv(x - pi * n, st.m_twdiv);
         buf[x] = m_mul<CLS>(buf[x], cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod], mc);
+      }
+    } else if (st.kind == ST_POW2F || st.kind == ST_POW2I) {
+      const int ntile = tot >> st.d;
+      const bool inv = st.kind == ST_POW2I;
+      for (int tile = threadIdx.x; tile < ntile; tile += blockDim.x) {
+        switch (st.d * 2 + (inv ? 1 : 0)) {
+          case 2: stage_pow2<CLS, 1, false>(st, buf, tile, cst, mc); break;
+          case 3: stage_pow2<CLS, 1, true>(st, buf, tile, cst, mc); break;
+          case 4: stage_pow2<CLS, 2, false>(st, buf, tile, cst, mc); break;
+          case 5: stage_pow2<CLS, 2, true>(st, buf, tile, cst, mc); break;
+          case 6: stage_pow2<CLS, 3, false>(st, buf, tile, cst, mc); break;
+          case 7: stage_pow2<CLS, 3, true>(st, buf, tile, cst, mc); break;
+          case 8: stage_pow2<CLS, 4, false>(st, buf, tile, cst, mc); break;
+          case 9: stage_pow2<CLS, 4, true>(st, buf, tile, cst, mc); break;
+          default: break;
+        }
       }
     } else {
       const int nvec = mdiv(tot, st.m_d);           // tot / d: exact, tot < 2^20

@@ -331,6 +331,52 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   P.prog_ginvpow.stages = prime_prog(ST_GINVPOW, true);
   P.prog_ginvdec.stages = prime_prog(ST_GINVDEC, true);
 
+  // ---- m = 2^e * odd in one launch: 2-power tiles + the odd primes' stages ----------------------
+  std::vector<Stage> fused_f, fused_i;
+  P.fused2 = false;
+  if (P.has_crt && split2 && pps[0].e >= 2) {
+    const int L = pps[0].e - 1;
+    const i64 h = (i64)1 << L;
+    // entry 2^(s-1) + i = omega_{2^e}^((h / 2^s) (2i+1)), s = 1..L, i < 2^(s-1); inverse table: the inverses,
+    // its level-1 entry times mhat^-1 (the X output of that level is scaled through mat_off)
+    auto table = [&](bool inverse) {
+      return per_comp([&](int t, std::vector<u64>& o) {
+        const u64 q = qs[(size_t)t];
+        o[0] = 1 % q;
+        for (int s = 1; s <= L; ++s) {
+          const i64 half = (i64)1 << (s - 1), step = h >> s;
+          for (i64 i = 0; i < half; ++i) {
+            const i64 ex = step * (2 * i + 1);
+            u64 w = (u64)(inverse ? P.ruinv : P.ru)[0][(size_t)(ex * T + t)];
+            if (inverse && s == 1) w = mulmod(w, (u64)P.mhatinv[(size_t)t], q);
+            o[(size_t)(half + i)] = w;
+          }
+        }
+      }, (size_t)h);
+    };
+    const int twf = table(false), twi = table(true);
+    const int mh = per_comp([&](int t, std::vector<u64>& o) { o[0] = (u64)P.mhatinv[(size_t)t]; }, 1);
+    auto tile = [&](int kind, int s_lo, int k, int tw_off, int mat_off) {
+      Stage s;
+      std::memset(&s, 0, sizeof(s));
+      s.kind = kind; s.p = s_lo; s.d = k; s.rts = (int32_t)1 << (s_lo - 1); s.wp_off = 0;
+      s.tw_off = tw_off; s.tw_mod = (int32_t)h; s.tw_div = 1; s.mat_off = mat_off;
+      return s;
+    };
+    // level groups, bottom up: 4 levels per tile, the remainder on top
+    std::vector<std::pair<int, int>> groups;
+    for (int s = 1; s <= L; s += 4) groups.push_back({s, std::min(4, L - s + 1)});
+    for (auto& g : groups) fused_f.push_back(tile(ST_POW2F, g.first, g.second, twf, -1));
+    fused_f.insert(fused_f.end(), crt_odd.st.begin(), crt_odd.st.end());
+    fused_i = crtinv_odd.st;
+    for (auto it = groups.rbegin(); it != groups.rend(); ++it)
+      fused_i.push_back(tile(ST_POW2I, it->first, it->second, twi, it->first == 1 ? mh : -1));
+    finish(fused_f); finish(fused_i);
+    P.fused2 = true;
+  }
+  P.prog_crt_fused.stages = fused_f;
+  P.prog_crtinv_fused.stages = fused_i;
+
   P.consts_per_comp = pool.size();
   P.host_consts.clear();
   for (int t = 0; t < T; ++t) P.host_consts.insert(P.host_consts.end(), pool.pool[(size_t)t].begin(), pool.pool[(size_t)t].end());
@@ -415,7 +461,7 @@ int plan_upload(Plan& P) {
   if ((rc = upload(&P.d_mod, mods))) return rc;
   if ((rc = upload(&P.d_consts, P.host_consts))) return rc;
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused};
   for (auto* sp : progs) if ((rc = upload_prog(*sp))) return rc;
   if ((rc = upload(&P.d_cconsts, P.host_cconsts))) return rc;
   if ((rc = upload(&P.d_rconsts, P.host_rconsts))) return rc;
@@ -513,7 +559,7 @@ void plan_free_device(Plan& P) {
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
   P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr;
   P.pow2 = Pow2Tables();

@@ -27,7 +27,15 @@ enum StageKind : int32_t {
   ST_GINVPOW = 8,  //                                            gInvPow (g.cpp:60-90)
   ST_GINVDEC = 9,  //                                            gInvDec (g.cpp:92-123)
   ST_SCALE = 10,   // out[x] = s * in[x]  (mhatInv crt.cpp:573-579, oddRad^-1 g.cpp:194-204)
-  ST_GAUSS = 11    // real (p-1) x (p-1) map of tensorGaussianDec           primeD (random.cpp:19-50)
+  ST_GAUSS = 11,   // real (p-1) x (p-1) map of tensorGaussianDec           primeD (random.cpp:19-50)
+  // Levels p .. p+d-1 (1-based, d <= 4) of the negacyclic 2-power transform on every contiguous block of
+  // tw_mod = 2^(e-1) coefficients (the innermost tensor factor of m = 2^e * odd, tensor.h:46-73), one
+  // 2^d-element register tile per thread: level s pairs x and x + 2^(s-1) inside blocks of 2^s with the
+  // twiddle table entry 2^(s-1) + (x mod 2^(s-1)) (the same merged-twist network as the m = 2^k kernels;
+  // CRT_{2^e} of crt.cpp:459-538 in a different but exact factorisation).  rts = 2^(p-1).  Z_q programs of
+  // the vector interpreter only (mixed_impl.h).
+  ST_POW2F = 12,   // forward: X' = X + w Y, Y' = X - w Y, levels ascending
+  ST_POW2I = 13    // inverse: X' = X + Y, Y' = w^-1 (X - Y), levels descending; mat_off >= 0: level 1 also carries mhat^-1
 };
 
 struct Stage {
@@ -92,6 +100,11 @@ struct Plan {
   // without mhat^-1, which the 2-power inverse kernel folds in).
   bool pow2_part = false;
   StageProgram prog_crt_odd, prog_crtinv_odd;
+  // m = 2^e * odd, e >= 2, in ONE launch of the vector interpreter: ST_POW2F/ST_POW2I tiles for the
+  // 2-power factor followed / preceded by the odd primes' stages.  This is what makes the poly-mul of the
+  // reference's own parameter sets (64*27, 64*81, 64*9*25, 128*7*13 ...) a fused 3-pass kernel.
+  bool fused2 = false;
+  StageProgram prog_crt_fused, prog_crtinv_fused;
   i64* d_gcrt = nullptr;                    // [n*T]
   i64* d_ginvcrt = nullptr;                 // [n*T]
   Pow2Tables pow2;

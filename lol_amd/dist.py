@@ -34,6 +34,10 @@ def allgather_batch(local, batch: int, group=None):
     if local.shape[0] != sizes[dist.get_rank(group)]:
         raise ValueError("local shard has the wrong batch size")
     mx = max(sizes) if sizes else 0
+    if sizes and min(sizes) == mx:          # equal shards (the usual case): no padding copy, no concatenation
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
