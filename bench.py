@@ -193,6 +193,18 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
         out[f"c4_polymul_{name}"] = _leg(timed(lambda: P4.polymul(x, x2, out=y, stream=st)), B4, 3 * slab4, q=q4)
         out[f"c4_crt_{name}"] = _leg(timed(lambda: P4.crt(x, stream=st)), B4, 2 * slab4, q=q4)
         del P4, x, x2, y
+    # ---- the reference's own benchmark index shapes, m = 2^e * odd (lol/.../Benchmarks/Default.hs:42-50:
+    # 64*9*25; lol-apps tunnelling chain 128*7*13), a reference-sized modulus, batch 8192 ----
+    for mref in (14400, 11648):
+        qr = lol_amd.good_q(mref, 1 << 26)
+        Pr = lol_amd.Plan(lol_amd.factor_pps(mref), [qr])
+        Br = 8192
+        x, x2 = rnd([qr], Br, Pr.n), rnd([qr], Br, Pr.n)
+        y = torch.empty_like(x)
+        slabr = Br * Pr.n * 8
+        out[f"ref_m{mref}_polymul"] = _leg(timed(lambda: Pr.polymul(x, x2, out=y, stream=st)), Br, 3 * slabr, q=qr, n=Pr.n)
+        out[f"ref_m{mref}_crt"] = _leg(timed(lambda: Pr.crt(x, stream=st)), Br, 2 * slabr, q=qr, n=Pr.n)
+        del Pr, x, x2, y
     # ---- config 5: key switch at m' = 2048, q = (1017857, 1032193); ring embedding 2048 -> 14336 ----
     qs5 = [1017857, 1032193]
     P5 = lol_amd.Plan([(2, 11)], qs5)

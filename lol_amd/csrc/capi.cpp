@@ -85,7 +85,7 @@ bool use_mixed(const Plan& P, const StageProgram& sp) {
 
 // m = 2^e * odd in one launch of the vector interpreter (plan.h: prog_crt_fused)
 bool use_fused2(const Plan& P) {
-  static const bool off = getenv("LOLHIP_NO_FUSED2") != nullptr;                     // A/B switch
+  const bool off = getenv("LOLHIP_NO_FUSED2") != nullptr;                            // A/B switch (read per call: tests flip it)
   return !off && P.fused2 && use_mixed(P, P.prog_crt_fused) && use_mixed(P, P.prog_crtinv_fused);
 }
 

@@ -218,26 +218,33 @@ def test_generic_indices(gpu, cpuref, m):
         assert np.array_equal(P.divGCRT(P.mulGCRT(y)), y)
 
 
-@pytest.mark.parametrize("m", [96, 160, 1728, 2912, 11648, 2 ** 12 * 3])
-def test_two_power_factor_through_the_fast_kernels(gpu, cpuref, monkeypatch, m):
-    """m = 2^e * odd with e >= 5: the innermost tensor factor CRT_{2^e} runs through the m = 2^k
-    kernels on contiguous blocks, the odd primes through the stage program.  Both routes (and
-    the all-stage-program route) against the oracle, every arithmetic class, ragged batch."""
+@pytest.mark.parametrize("m", [12, 40, 48, 96, 160, 768, 1728, 2912, 11648, 14336, 2 ** 12 * 3])
+def test_two_power_factor_routes(gpu, cpuref, monkeypatch, m):
+    """m = 2^e * odd: the innermost tensor factor CRT_{2^e} acts on contiguous blocks of 2^(e-1)
+    coefficients.  Three routes against the oracle, every arithmetic class, ragged batch:
+    "fused" (default, e >= 2): register tiles of up to four levels inside the vector interpreter, one
+    launch, fused poly-mul; "split" (e >= 5): the m = 2^k kernels for the 2-power factor and the stage
+    program for the odd primes; "stages": the reference's own factorisation, stage by stage.
+    The m cover one to three tiles per transform with 1, 2, 3 and 4 levels in the last one."""
     pps = lm.factor_pps(m)
     for qs in ([lm.first_good_q(m, 2 ** 20)], [lm.first_good_q(m, 2 ** 29), lm.first_good_q(m, 2 ** 31)],
-               [lm.first_good_q(m, 2 ** 60), lm.first_good_q(m, 2 ** 61)]):
+               [lm.first_good_q(m, 2 ** 45)], [lm.first_good_q(m, 2 ** 60), lm.first_good_q(m, 2 ** 61)]):
         R = Params(pps, qs)
         rng = np.random.default_rng(m + len(qs))
         y, z = R.random(rng, 5), R.random(rng, 5)
         want = cpuref.crt(R, y), cpuref.crtinv(R, y), cpuref.polymul(R, y, z)
-        for route in ("split", "stages"):
+        for route in ("fused", "split", "stages"):
+            if route != "fused":
+                monkeypatch.setenv("LOLHIP_NO_FUSED2", "1")
             if route == "stages":
                 monkeypatch.setenv("LOLHIP_NO_POW2_PART", "1")
             P = gpu.Plan(pps, qs)
             assert np.array_equal(P.crt(y), want[0]), (m, qs, route)
             assert np.array_equal(P.crtInv(y), want[1]), (m, qs, route)
             assert np.array_equal(P.polymul(y, z), want[2]), (m, qs, route)
+            assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y)), (m, qs, route)
             monkeypatch.delenv("LOLHIP_NO_POW2_PART", raising=False)
+            monkeypatch.delenv("LOLHIP_NO_FUSED2", raising=False)
 
 
 @pytest.mark.parametrize("m,q", BENCH1)
