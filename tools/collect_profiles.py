@@ -102,6 +102,28 @@ for name in ("microbench_ops.txt", "microbench_bfly2.txt"):
     if os.path.exists(src):
         open(os.path.join(DST, f"{tag}_{name}"), "w").write(open(src).read())
 
+# 3c. the reference's own index shapes: timing table + trace/counters of the fused poly-mul at m = 14400
+rp = os.path.join(SRC, "refparams.txt")
+if os.path.exists(rp):
+    with open(os.path.join(DST, f"{tag}_refparams.txt"), "w") as fh:
+        fh.write("# tools/bench_refparams2.sh: m = 2^e * odd, batch 8192, one modulus just above 2^26 / 2^58; 'fused' = one launch of the vector\n"
+                 "# interpreter with ST_POW2 tiles (default), 'split' = LOLHIP_NO_FUSED2=1 (m = 2^k kernels + odd stage program, unfused poly-mul)\n")
+        fh.write(open(rp).read())
+        ent = {}
+        for f in glob.glob(os.path.join(SRC, "ref_kt", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_mixed" in r["Name"]:
+                    ent = {"kernel": (re.search(r"k_mixed<[^>]*>", r["Name"]) or [r["Name"][:60]])[0], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
+        alg = 3 * 8192 * 3840 * 8
+        fh.write(f"# rocprofv3 --kernel-trace --stats -- tools/bench_kernels m14400 1 8192 polymul 50 26: {json.dumps(ent)}\n")
+        f_, w_ = pmc("ref_pmc_FETCH_SIZE", "k_mixed"), pmc("ref_pmc_WRITE_SIZE", "k_mixed")
+        if "FETCH_SIZE" in f_ and "WRITE_SIZE" in w_:
+            hb = (2 * f_["FETCH_SIZE"][0] + w_["WRITE_SIZE"][0]) * 1024
+            fh.write(f"# FETCH_SIZE {f_['FETCH_SIZE'][0]:.1f} KB (x2 rule), WRITE_SIZE {w_['WRITE_SIZE'][0]:.1f} KB per launch: {hb / alg:.3f} x algorithmic ({alg} B)\n")
+        sqv = pmc("ref_sq", "k_mixed")
+        for k in sorted(sqv):
+            fh.write(f"# {k:24s} {sqv[k][0]:.6g}\n")
+
 # 4. pipeline kernels
 pl = os.path.join(SRC, "pipelines.jsonl")
 if os.path.exists(pl):

@@ -17,7 +17,7 @@ label = sys.argv[2] if len(sys.argv) > 2 else src
 inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(src))), "include")
 MUL = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_i64_i32", "v_mul_hi_i32"}
 print(f"== {label}")
-for ar in (1, 2, 3):
+for ar in (1, 2, 3, 4):
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", f"-I{inc}", f"-I{src}", "-S", "--cuda-device-only",
                         os.path.join(src, f"pow2_ar{ar}.hip"), "-o", tmp.name], check=True, capture_output=True)

@@ -32,6 +32,14 @@ for qb in 30 60; do for op in crt polymul; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/c4_sq_${op}_$qb -- $R/tools/bench_kernels m15015 1 1024 $op 5 $qb > /dev/null 2>&1
 done; done
 echo "config 4 done"
+# ---- the reference's own index shapes (m = 2^e * odd): fused one-launch route vs the split route ----
+(cd $R && tools/bench_refparams2.sh) > $O/refparams.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ref_kt -- $R/tools/bench_kernels m14400 1 8192 polymul 50 26 > $O/ref_kt.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/ref_sq -- $R/tools/bench_kernels m14400 1 8192 polymul 5 26 > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $O/ref_pmc_$c -- $R/tools/bench_kernels m14400 1 8192 polymul 5 26 > /dev/null 2>&1
+done
+echo "reference shapes done"
 python3 $R/tools/bench_pipelines.py > $O/pipelines.jsonl 2> $O/pipelines.err
 $R/tools/microbench_ops > $O/microbench_ops.txt 2>&1
 $R/tools/microbench_bfly2 > $O/microbench_bfly2.txt 2>&1
