@@ -95,7 +95,7 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
     MixedLaunch m;
     m.stream = s; m.y = y; m.a = src ? src : y; m.b = nullptr; m.B = B; m.T = P.T; m.n = P.n;
     m.st_a = sp.d_stages; m.n_a = sp.nstages; m.st_b = nullptr; m.n_b = 0;
-    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = false;
+    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = false;
     return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
   GenericLaunch a;
@@ -248,7 +248,7 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
     m.stream = s; m.y = c; m.a = a; m.b = b; m.B = B; m.T = P.T; m.n = P.n;
     m.st_a = pf.d_stages; m.n_a = pf.nstages;
     m.st_b = pi.d_stages; m.n_b = pi.nstages;
-    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true;
+    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true;
     return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
   // otherwise: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp is a

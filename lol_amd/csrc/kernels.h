@@ -70,7 +70,8 @@ struct MixedLaunch {
   i64 n;
   const Stage* st_a; int n_a;     // the program, or crt for the fused poly-mul
   const Stage* st_b; int n_b;     // crtInv for the fused poly-mul
-  const u64* consts;
+  const u64* consts;              // the pool (classes 2 and 3: the Montgomery copy)
+  const uint32_t* consts32;       // its 32-bit copy (classes 1 and 2), else null
   int cpc;
   const ModCtx* mod;
   int cls;               // Plan::mixed_cls (plan.cpp): 0/1 exact division, 2/3 Montgomery with `consts` = the

@@ -33,13 +33,19 @@
 namespace lolhip {
 
 #ifndef LOLHIP_MIXED_W2
-#define LOLHIP_MIXED_W2 8
+#define LOLHIP_MIXED_W2 6      // waves/SIMD bound of the 32-bit single-program kernel (A/B with the 32-bit pool: 6 beats 8, which spills to scratch)
 #endif
 // coefficients a thread loads/stores: ppw * n <= KMAX * blockDim, KMAX in {12, 16} picked by the launcher
 // (m = 15015: 5760 / 512 = 11.25 -> 12: a quarter fewer predicated load/store/convert slots than 16)
 
 template <int CLS> using MV = std::conditional_t<CLS == 0 || CLS == 3, u64, u32>;
 template <int CLS> constexpr bool wide() { return CLS == 0 || CLS == 3; }
+// element type of the constant pool the kernel reads: the 32-bit classes get a 32-bit copy (half the
+// scalar-load bytes and SGPRs of a matrix row, half the bytes of a per-lane twiddle load)
+#ifndef LOLHIP_MIXED_POOL32
+#define LOLHIP_MIXED_POOL32 1
+#endif
+template <int CLS> using PT = std::conditional_t<(CLS == 1 || CLS == 2) && LOLHIP_MIXED_POOL32, u32, u64>;
 
 // x / v for x <= 8192 (every index here is below ppw * n <= 8192) from the plan's 2^40-scaled
 // reciprocal M = floor(2^40/v)+1: (M >> 8) + 1 is floor(2^32/v) + 1 or + 2, whose error times x
@@ -117,7 +123,7 @@ template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(M
 
 // one output of a dense stage: sum_c v[c] * row[c] mod q
 template <int CLS, int D>
-__device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const u64* __restrict__ row, const ModCtx& mc) {
+__device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const PT<CLS>* __restrict__ row, const ModCtx& mc) {
   static_assert(D <= 16, "16 products below 2^124 fit in 128 bits");
   if constexpr (CLS == 2) {
     u64 acc = 0;
@@ -140,7 +146,7 @@ __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const u64* __res
 // one d-vector of one stage, in place in LDS
 template <int CLS, int D>
 __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__ buf, int vec, int n, u64 n_magic,
-                                          const u64* __restrict__ cst, const ModCtx& mc) {
+                                          const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   const u64 q = mc.q;
   const int rts = st.rts;
@@ -156,7 +162,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
     case ST_DFTP:
     case ST_CRTP:
     case ST_CRTPINV: {
-      const u64* M = cst + st.mat_off;
+      const PT<CLS>* M = cst + st.mat_off;
 #pragma unroll
       for (int i = 0; i < D; ++i) o[i] = m_dot<CLS, D>(v, M + i * D, mc);
       break;
@@ -242,7 +248,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
 // odd primes' stages in any order.
 template <int CLS, int K, bool INV>
 __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict__ buf, int tile,
-                                           const u64* __restrict__ cst, const ModCtx& mc) {
+                                           const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   constexpr int NE = 1 << K;
   const u64 q = mc.q;
@@ -268,7 +274,7 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
 #pragma unroll
     for (int j = 0; j < NE; ++j) v[j] = base[j * rts];
   }
-  const u64* tw = cst + st.tw_off + low;
+  const PT<CLS>* tw = cst + st.tw_off + low;
   if constexpr (!INV) {
 #pragma unroll
     for (int l = 0; l < K; ++l) {
@@ -322,10 +328,17 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
 }
 
 // every stage of one program over the `tot` packed coefficients in buf; ends with a barrier
-template <int CLS>
+// HOIST: the dispatch on the vector length / tile size OUTSIDE the loop over vectors.  The compiler then keeps
+// the stage's constants (a whole d x d matrix: 169 SGPRs at p = 13) in registers across the loop: good
+// where there are VGPRs to spill SGPRs into (the fused poly-mul at 128: -3..6 %), bad at the 64-80 of the
+// single-program kernels (scratch spills: crt of m = 15015 0.042 -> 0.058 ms).
+template <int CLS, bool HOIST>
 __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, int n, u64 n_magic,
                                            const Stage* __restrict__ stages, int nstages,
-                                           const u64* __restrict__ cst, const ModCtx& mc) {
+                                           const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
+#define LOLHIP_LOOP(COUNT, CALL) for (int it = threadIdx.x; it < (COUNT); it += blockDim.x) { CALL; }
+#define LOLHIP_TILES(X) X(2, 1, false) X(3, 1, true) X(4, 2, false) X(5, 2, true) X(6, 3, false) X(7, 3, true) X(8, 4, false) X(9, 4, true)
+#define LOLHIP_VECS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(10) X(11) X(12) X(13)
   for (int s = 0; s < nstages; ++s) {
     const Stage st = stages[s];
     if (st.kind == ST_DIAG || st.kind == ST_SCALE) {
@@ -336,40 +349,33 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       }
     } else if (st.kind == ST_POW2F || st.kind == ST_POW2I) {
       const int ntile = tot >> st.d;
-      const bool inv = st.kind == ST_POW2I;
-      for (int tile = threadIdx.x; tile < ntile; tile += blockDim.x) {
-        switch (st.d * 2 + (inv ? 1 : 0)) {
-          case 2: stage_pow2<CLS, 1, false>(st, buf, tile, cst, mc); break;
-          case 3: stage_pow2<CLS, 1, true>(st, buf, tile, cst, mc); break;
-          case 4: stage_pow2<CLS, 2, false>(st, buf, tile, cst, mc); break;
-          case 5: stage_pow2<CLS, 2, true>(st, buf, tile, cst, mc); break;
-          case 6: stage_pow2<CLS, 3, false>(st, buf, tile, cst, mc); break;
-          case 7: stage_pow2<CLS, 3, true>(st, buf, tile, cst, mc); break;
-          case 8: stage_pow2<CLS, 4, false>(st, buf, tile, cst, mc); break;
-          case 9: stage_pow2<CLS, 4, true>(st, buf, tile, cst, mc); break;
-          default: break;
-        }
+      const int sel = st.d * 2 + (st.kind == ST_POW2I ? 1 : 0);
+      if constexpr (HOIST) {
+#define LOLHIP_X(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV>(st, buf, it, cst, mc))) break;
+        switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; }
+#undef LOLHIP_X
+      } else {
+#define LOLHIP_X(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV>(st, buf, it, cst, mc); break;
+        LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; })
+#undef LOLHIP_X
       }
     } else {
       const int nvec = mdiv(tot, st.m_d);           // tot / d: exact, tot < 2^20
-      for (int vec = threadIdx.x; vec < nvec; vec += blockDim.x) {
-        switch (st.d) {
-          case 2: stage_vec<CLS, 2>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 3: stage_vec<CLS, 3>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 4: stage_vec<CLS, 4>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 5: stage_vec<CLS, 5>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 6: stage_vec<CLS, 6>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 7: stage_vec<CLS, 7>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 10: stage_vec<CLS, 10>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 11: stage_vec<CLS, 11>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 12: stage_vec<CLS, 12>(st, buf, vec, n, n_magic, cst, mc); break;
-          case 13: stage_vec<CLS, 13>(st, buf, vec, n, n_magic, cst, mc); break;
-          default: break;   // excluded on the host (mixed_ok)
-        }
+      if constexpr (HOIST) {
+#define LOLHIP_X(D) case D: LOLHIP_LOOP(nvec, (stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
+        switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }      // other lengths are excluded on the host (mixed_ok)
+#undef LOLHIP_X
+      } else {
+#define LOLHIP_X(D) case D: stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
+        LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; })
+#undef LOLHIP_X
       }
     }
     __syncthreads();
   }
+#undef LOLHIP_LOOP
+#undef LOLHIP_TILES
+#undef LOLHIP_VECS
 }
 
 template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
@@ -389,7 +395,7 @@ template <int CLS, int MODE, int KMAX>
 __global__ void __launch_bounds__(512, (MODE == 0 && CLS == 2) ? LOLHIP_MIXED_W2 : (MODE == 0 && CLS == 1) ? 6 : 4)
 k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int ppw, i64 ngroups,
         const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
-        const u64* __restrict__ consts, int cpc, const ModCtx* __restrict__ mod) {
+        const u64* __restrict__ consts64, const u32* __restrict__ consts32, int cpc, const ModCtx* __restrict__ mod) {
   using V = MV<CLS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V* buf = reinterpret_cast<V*>(smem);
@@ -403,7 +409,8 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
     const int np = (int)((B - b0) < ppw ? (B - b0) : ppw);
     const int tot = np * n;
     const ModCtx mc = mod[t];
-    const u64* cst = consts + (size_t)t * cpc;
+    const PT<CLS>* cst;
+    if constexpr (sizeof(PT<CLS>) == 4) cst = consts32 + (size_t)t * cpc; else cst = consts64 + (size_t)t * cpc;
     // Global memory through buffer descriptors over this group's window: one 32-bit lane offset
     // plus a wave-uniform step per batch entry (no 64-bit addresses in VGPRs), and the range
     // check does the x < tot predicate: loads past the window return 0, stores are dropped.
@@ -436,7 +443,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
     if constexpr (MODE == 0) {
       to_lds(ra);
       __syncthreads();
-      run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       store16();
     } else {
       const bool square = (a_in == b_in);
@@ -445,7 +452,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
       if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       __syncthreads();
-      run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       V ah[KMAX];                        // a-hat: every thread keeps the positions it owns
       {
         const int x0 = fresh(tid);
@@ -456,7 +463,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         __syncthreads();                 // every a-hat coefficient is in registers before b overwrites the buffer
         to_lds(ra);
         __syncthreads();
-        run_stages<CLS>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+        run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       }
       {
         const int x0 = fresh(tid);
@@ -464,7 +471,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
       }
       __syncthreads();
-      run_stages<CLS>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
+      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
       store16();
     }
     __syncthreads();                     // the buffer is reused by the next item
@@ -486,7 +493,7 @@ hipError_t launch_cls(const MixedLaunch& a) {
   const size_t per_thread = (coeffs + threads - 1) / threads;
 #define LOLHIP_MIXED_LAUNCH(K)                                                                                         \
   hipLaunchKernelGGL((k_mixed<CLS, MODE, K>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.a, a.b, \
-                     a.B, a.T, (int)a.n, ppw, ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.cpc, a.mod)
+                     a.B, a.T, (int)a.n, ppw, ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.consts32, a.cpc, a.mod)
   if (per_thread <= 12) LOLHIP_MIXED_LAUNCH(12);
   else LOLHIP_MIXED_LAUNCH(16);
 #undef LOLHIP_MIXED_LAUNCH

@@ -546,6 +546,19 @@ int plan_upload(Plan& P) {
       }
     }
     if ((rc = upload(&P.d_consts_mont, mont))) return rc;
+    if (P.mixed_cls == 2) {
+      std::vector<uint32_t> c32(mont.begin(), mont.end());           // every entry is a residue below q < 2^32
+      if ((rc = upload(&P.d_consts32, c32))) return rc;
+    }
+  }
+  if (P.mixed_cls == 1) {
+    std::vector<uint32_t> c32(P.host_consts.size());
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < P.consts_per_comp; ++i) {
+        const size_t o = (size_t)t * P.consts_per_comp + i;
+        c32[o] = (uint32_t)(P.host_consts[o] % P.qs[(size_t)t]);
+      }
+    if ((rc = upload(&P.d_consts32, c32))) return rc;
   }
   HIPCK(hipGetDevice(&P.device_id));
   P.device = true;
@@ -554,7 +567,7 @@ int plan_upload(Plan& P) {
 
 void plan_free_device(Plan& P) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(P.d_mod); fr(P.d_consts); fr(P.d_consts_mont); fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_cconsts); fr(P.d_rconsts);
+  fr(P.d_mod); fr(P.d_consts); fr(P.d_consts_mont); fr(P.d_consts32); P.d_consts32 = nullptr; fr(P.d_gcrt); fr(P.d_ginvcrt); fr(P.d_cconsts); fr(P.d_rconsts);
   P.d_cconsts = nullptr; P.d_rconsts = nullptr; P.d_consts_mont = nullptr;
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);

@@ -92,6 +92,7 @@ struct Plan {
   ModCtx* d_mod = nullptr;                  // [T]
   u64* d_consts = nullptr;                  // generic-path constant pool, [T][consts_per_comp]
   u64* d_consts_mont = nullptr;             // the same pool times 2^64 mod q_t (every q_t odd): Montgomery class of mixed.hip
+  uint32_t* d_consts32 = nullptr;           // 32-bit copy of the pool the 32-bit classes of the vector interpreter read (class 2: the Montgomery one)
   int consts_per_comp = 0;
   StageProgram prog_crt, prog_crtinv, prog_l, prog_linv, prog_gpow, prog_gdec, prog_ginvpow, prog_ginvdec;
   // m = 2^e * odd, 5 <= e <= 15: the 2-power tensor factor is innermost (tensor.h:46-73), i.e. it
