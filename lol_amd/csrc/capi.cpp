@@ -126,7 +126,7 @@ int run_pow2(const Plan& P, int mode, hipStream_t s, int64_t* y, const int64_t* 
     l.arith = P.pow2.arith32; l.tw_fwd = P.pow2.d_tw_fwd32; l.tw_inv = P.pow2.d_tw_inv32; l.scale = P.pow2.d_scale32;
   } else {
     l.arith = 1;
-    for (u64 q : P.qs) if (q >= (1ull << 61)) l.arith = 0;
+    for (u64 q : P.qs) if (q >= (1ull << 61) || !(q & 1)) l.arith = 0;      // class 1's pointwise product is a Montgomery step: odd q
     l.tw_fwd = P.pow2.d_tw_fwd; l.tw_inv = P.pow2.d_tw_inv; l.scale = P.pow2.d_scale;
   }
   return launch_pow2(l, mode) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;

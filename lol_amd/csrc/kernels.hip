@@ -96,7 +96,7 @@ k_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64*
   tw.pf = tw_fwd + (size_t)s * n * 2;
   tw.pi = tw.pf;
   tw.lds_tw = lds_tw;
-  tw.sc0 = 0; tw.sc1 = 0;
+  tw.sc0 = 0; tw.sc1 = 0; tw.l1w = 0; tw.l1wp = 0;
   if constexpr (L >= TWL_MIN_L) tw_fill_lds<NT>(lds_tw, tw.fwd, tw.comp, n, tau);
 
   constexpr Lay LIO = S::io();

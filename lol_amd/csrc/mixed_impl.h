@@ -42,6 +42,9 @@ template <int CLS> using MV = std::conditional_t<CLS == 0 || CLS == 3, u64, u32>
 template <int CLS> constexpr bool wide() { return CLS == 0 || CLS == 3; }
 // element type of the constant pool the kernel reads: the 32-bit classes get a 32-bit copy (half the
 // scalar-load bytes and SGPRs of a matrix row, half the bytes of a per-lane twiddle load)
+#ifndef LOLHIP_MIXED_HOIST0
+#define LOLHIP_MIXED_HOIST0 0     // hoisted dispatch in the single-program kernels too (A/B)
+#endif
 #ifndef LOLHIP_MIXED_POOL32
 #define LOLHIP_MIXED_POOL32 1
 #endif
@@ -443,7 +446,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
     if constexpr (MODE == 0) {
       to_lds(ra);
       __syncthreads();
-      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       store16();
     } else {
       const bool square = (a_in == b_in);
@@ -452,7 +455,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
       if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       __syncthreads();
-      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       V ah[KMAX];                        // a-hat: every thread keeps the positions it owns
       {
         const int x0 = fresh(tid);
@@ -463,7 +466,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         __syncthreads();                 // every a-hat coefficient is in registers before b overwrites the buffer
         to_lds(ra);
         __syncthreads();
-        run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+        run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       }
       {
         const int x0 = fresh(tid);
@@ -471,7 +474,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
       }
       __syncthreads();
-      run_stages<CLS, MODE == 2>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
+      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
       store16();
     }
     __syncthreads();                     // the buffer is reused by the next item

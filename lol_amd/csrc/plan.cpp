@@ -471,12 +471,22 @@ int plan_upload(Plan& P) {
   if (P.is_pow2 || P.pow2_part) {
     const int L = P.pow2.L;
     const i64 n = (i64)1 << L;          // length of the 2-power factor (= P.n for m = 2^k)
-    std::vector<u64> fwd((size_t)(T * n * 2), 0), inv((size_t)(T * n * 2), 0), sc((size_t)(T * 2), 0);
+    // per component 8 words: Shoup pairs of S = mhat^-1, of the level-1 inverse twiddle times S, and of the
+    // same two times 2^64 mod q (the 64-bit fused poly-mul's pointwise product is a Montgomery reduction,
+    // which leaves a factor 2^-64 that the last inverse level takes back for free)
+    std::vector<u64> fwd((size_t)(T * n * 2), 0), inv((size_t)(T * n * 2), 0), sc((size_t)(T * 8), 0);
     for (int t = 0; t < T; ++t) {
       const u64 q = P.qs[(size_t)t];
       const u64 S = (u64)P.mhatinv[(size_t)t];
-      ShoupW ss = make_shoup(S, q);
-      sc[(size_t)(t * 2)] = ss.w; sc[(size_t)(t * 2 + 1)] = ss.wp;
+      {
+        const u64 w1 = mulmod((u64)P.ruinv[0][(size_t)((n >> 1) * T + t)], S, q);      // psi_2^-1 * S: the level-1 entry below
+        const u64 R = (u64)((((unsigned __int128)1) << 64) % q);
+        const u64 vals[4] = {S, w1, mulmod(S, R, q), mulmod(w1, R, q)};
+        for (int k = 0; k < 4; ++k) {
+          ShoupW ss = make_shoup(vals[k], q);
+          sc[(size_t)(t * 8 + 2 * k)] = ss.w; sc[(size_t)(t * 8 + 2 * k + 1)] = ss.wp;
+        }
+      }
       for (int s = 1; s <= L; ++s) {
         const i64 N = (i64)1 << s, half = N >> 1, step = n / N;
         for (i64 i = 0; i < half; ++i) {
@@ -507,8 +517,10 @@ int plan_upload(Plan& P) {
           f32[o] = (uint32_t)fwd[o]; f32[o + 1] = (uint32_t)((fwd[o] << 32) / q);
           i32[o] = (uint32_t)inv[o]; i32[o + 1] = (uint32_t)((inv[o] << 32) / q);
         }
-        s32[(size_t)t * 2] = (uint32_t)sc[(size_t)t * 2];
-        s32[(size_t)t * 2 + 1] = (uint32_t)((sc[(size_t)t * 2] << 32) / q);
+        for (int k = 0; k < 4; ++k) {      // (the 2^64-scaled pairs are not used by the 32-bit classes)
+          s32[(size_t)t * 8 + 2 * k] = (uint32_t)sc[(size_t)t * 8 + 2 * k];
+          s32[(size_t)t * 8 + 2 * k + 1] = (uint32_t)((sc[(size_t)t * 8 + 2 * k] << 32) / q);
+        }
       }
       if ((rc = upload(&P.pow2.d_tw_fwd32, f32))) return rc;
       if ((rc = upload(&P.pow2.d_tw_inv32, i32))) return rc;

@@ -65,7 +65,7 @@ struct Pow2Tables {
   // per component t, n Shoup pairs: entry (N/2 + i) = psi_N^(2i+1), N = 2..n (entry 0 unused)
   u64* d_tw_fwd = nullptr;         // [T][n][2]
   u64* d_tw_inv = nullptr;         // [T][n][2]  inverse twiddles; the level-1 entry is pre-scaled
-  u64* d_scale = nullptr;          // [T][2]     Shoup pair of mhatInv
+  u64* d_scale = nullptr;          // [T][8]     Shoup pairs of mhatInv, the level-1 inverse twiddle times mhatInv, and both times 2^64 (plan.cpp)
   // the same three tables as 32-bit Shoup pairs (w, floor(w*2^32/q)) when every q_t < 2^31
   uint32_t *d_tw_fwd32 = nullptr, *d_tw_inv32 = nullptr, *d_scale32 = nullptr;
   int arith32 = 0;                 // 4: every q_t < 2^27; 2: < 2^30; 3: < 2^31; 0: no 32-bit tables

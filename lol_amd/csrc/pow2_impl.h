@@ -290,6 +290,7 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR
 // so that the pointwise product below is a bare Montgomery reduction
 template <int AR> __device__ __forceinline__ VT<AR> park_fwd(VT<AR> v, const QKT<AR>& k) {
   if constexpr (AR >= 2) return csub32(shoup32(v, k.r, k.rp, k.q), k.q);
+  else if constexpr (AR == 1) return csubn(csubn(v, k.nq4), k.nq2);      // [0,8q) -> [0,2q): all the Montgomery product needs
   else return canon_fwd<AR>(v, k);
 }
 // pointwise product of a parked a-hat and a lazy b-hat (forward range), any range the
@@ -305,7 +306,16 @@ template <int AR> __device__ __forceinline__ VT<AR> pmul(VT<AR> a, VT<AR> b, con
     if constexpr (AR == 3) return csub32(t, k.q);      // this class's inverse takes canonical values
     else return t;                                     // [0,2q): the inverse's lazy range
   } else if constexpr (AR == 1) {
-    return mulmod(a, b, mc);                           // a < q, b < 8q: a*b < q * 2^64
+#ifdef LOLHIP_ABL_PMUL      // ablation: what the pointwise product costs (0.028 of 0.52 ms with the exact division)
+    return a + b;
+#endif
+    // a < 2q, b < 8q, q < 2^61: T = a b < 16 q^2 < 2^126.  Montgomery: m = T (-q^-1) mod 2^64;
+    // (T + m q) / 2^64 = hi(T) + hi(m q) + [lo(T) != 0]  <  16 q^2 / 2^64 + q + 1 < 3q + 1: inside the inverse's
+    // lazy range [0,4q) as it stands.  The factor 2^-64 is taken back by the last inverse level, whose
+    // two constants the plan pre-multiplies by 2^64 mod q.  ~22 instructions against ~40 for the exact division.
+    const unsigned __int128 T = (unsigned __int128)a * b;
+    const u64 lo = (u64)T;
+    return (u64)(T >> 64) + __umul64hi(lo * mc.nqinv, mc.q) + (lo != 0);
   } else {
     return mulmod(a, canon_fwd<0>(b, k), mc);
   }
@@ -359,7 +369,8 @@ template <typename V> struct TwCtxT {
   const V *pf, *pi;     // this component's tables as plain pointers (scalar loads)
   const V* lds_tw;      // LDS copy of entries [16,512) of the table currently in use
   u32 comp;             // byte offset of this RNS component's table
-  V sc0, sc1;           // Shoup pair of mhat^-1
+  V sc0, sc1;           // Shoup pair of mhat^-1 (times 2^64 in the 64-bit fused poly-mul)
+  V l1w, l1wp;          // Shoup pair of the level-1 inverse twiddle times the same factor
 };
 template <Lay A, int K> constexpr bool tw_uniform() {
   for (int j = 0; j < A.ntb; ++j) if (A.thr[j] < A.reg[K]) return false;
@@ -462,7 +473,7 @@ __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t,
     if (HALF >= 0 && ordb / (8 / LOLHIP_LEVEL_PARTS) != HALF) continue;
     const int s = level_tab<A, K>.slot[e];
     if constexpr (!INV) bfly_fwd<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
-    else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], tw.sc0, tw.sc1, qk);
+    else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], tw.l1w, tw.l1wp, tw.sc0, tw.sc1, qk);
     else bfly_inv<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
   }
 }
@@ -805,8 +816,11 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   // Visibility: for L > 10 a workgroup barrier follows before first use; for L <= 10 the
   // polynomial's own wave does both the fill and the reads.
   if constexpr (L >= TWL_MIN_L) tw_fill_lds<NT>(lds_tw, (MODE == 1) ? tw.inv : tw.fwd, tw.comp, n, tau);
-  tw.sc0 = scale[(size_t)t * 2];
-  tw.sc1 = scale[(size_t)t * 2 + 1];
+  constexpr int SC = (MODE == 2 && AR == 1) ? 4 : 0;       // the 2^64-scaled pairs: see pmul
+  tw.sc0 = scale[(size_t)t * 8 + SC];
+  tw.sc1 = scale[(size_t)t * 8 + SC + 1];
+  tw.l1w = scale[(size_t)t * 8 + SC + 2];
+  tw.l1wp = scale[(size_t)t * 8 + SC + 3];
 
   constexpr Lay LIO = S::io();              // global I/O of powerful-basis data
   constexpr Lay LFIN = S::final_layout();   // where the forward transform leaves the CRT coefficients
