@@ -285,6 +285,12 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR
   if constexpr (AR >= 2) return (u32)x + (k.q & (u32)(x >> 63));
   else return canon_in(x, k.q);
 }
+// the same on the way INTO a forward transform: the 64-bit lazy class takes any value in [0,8q), and
+// x + 4q is in (3q,5q) for every x in (-q,q): one v_lshl_add_u64 instead of a sign test and a masked add
+template <int AR> __device__ __forceinline__ VT<AR> from_i64_fwd(i64 x, const QKT<AR>& k) {
+  if constexpr (AR == 1) return add64u((u64)x, k.q4);
+  else return from_i64<AR>(x, k);
+}
 // the operand of the fused poly-mul that waits in registers: canonical in the 64-bit classes; in the
 // 32-bit ones canonical AND multiplied by 2^32 (one Shoup product, valid for any lazy 32-bit value),
 // so that the pointwise product below is a bare Montgomery reduction
@@ -842,7 +848,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   if constexpr (MODE == 0 || MODE == 2) {
     const rsrc_t src = (MODE == 2) ? ra : ry;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk);
+    for (int e = 0; e < E; ++e) v[e] = from_i64_fwd<AR>((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk);
     LH_STAMP(1);
     fwd_transform<AR, L, LIO>(v, lds, tw, tau, qk);
     if constexpr (MODE == 0) LH_STAMP(20);
@@ -866,7 +872,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
       // sinks each load to its use and the wave pays 16 serial HBM round trips
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)raw[e], qk);
+      for (int e = 0; e < E; ++e) v[e] = from_i64_fwd<AR>((i64)raw[e], qk);
       LH_STAMP(11);
       fwd_transform<AR, L, LIO, 10, true>(v, lds, tw, tau, qk);
     }
