@@ -291,6 +291,11 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64_fwd(i64 x, const QK
   if constexpr (AR == 1) return add64u((u64)x, k.q4);
   else return from_i64<AR>(x, k);
 }
+// and into an inverse transform (range [0,4q)): x + 2q is in (q,3q)
+template <int AR> __device__ __forceinline__ VT<AR> from_i64_inv(i64 x, const QKT<AR>& k) {
+  if constexpr (AR == 1) return add64u((u64)x, k.q2);
+  else return from_i64<AR>(x, k);
+}
 // the operand of the fused poly-mul that waits in registers: canonical in the 64-bit classes; in the
 // 32-bit ones canonical AND multiplied by 2^32 (one Shoup product, valid for any lazy 32-bit value),
 // so that the pointwise product below is a bare Montgomery reduction
@@ -890,7 +895,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   }
   if constexpr (MODE == 1) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64<AR>((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk);
+    for (int e = 0; e < E; ++e) v[e] = from_i64_inv<AR>((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk);
   }
   if constexpr (MODE == 0) {
 #pragma unroll
