@@ -182,7 +182,8 @@ __device__ __forceinline__ u32 csub32(u32 x, u32 m) { return min(x, x - m); }   
 __device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return w * y - __umulhi(wp, y) * q; }
 
 // forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
-template <int AR>
+// WS: the twiddle is wave-uniform (SGPR operands in the 64-bit class's multiply chains, zq_dev.h)
+template <int AR, bool WS = false>
 __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
   if constexpr (AR == 3) {
     const u32 x = csub32(X, k.q);                     // [0,2q) -> [0,q)
@@ -201,7 +202,7 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     Y = x - t + k.q2;
   } else if constexpr (AR == 1) {
     const u64 x = csubn(X, k.nq4);                    // [0,8q) -> [0,4q)
-    const u64 xn = shoup_acc(Y, w, wp, k.nq, x);      // x + t, t in [0,4q)
+    const u64 xn = shoup_acc<WS>(Y, w, wp, k.nq, x);  // x + t, t in [0,4q)
     const u64 z = shl1_add64u(x, k.q4);                // 2x + 4q
     X = xn;
     Y = z - xn;                                       // x - t + 4q
@@ -213,7 +214,7 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
   }
 }
 // inverse (Gentleman-Sande) butterfly:  X' = X + Y,  Y' = (X - Y) * w
-template <int AR>
+template <int AR, bool WS = false>
 __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, const QKT<AR>& k) {
   if constexpr (AR == 3) {                            // canonical in, canonical out
     const u32 s = X + Y;
@@ -229,7 +230,7 @@ __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     const u64 s = add64(X, Y);                        // [0,8q)
     const u64 d = add64u(X, k.q4) - Y;                 // (0,8q)
     X = csubn(s, k.nq4);
-    Y = shoup_acc(d, w, wp, k.nq, 0);
+    Y = shoup_acc<WS>(d, w, wp, k.nq, 0);
   } else {
     const u64 s = X + Y;
     const u64 d = X - Y + k.q2;
@@ -239,7 +240,7 @@ __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
 }
 // last inverse level: both outputs additionally scaled by mhat^-1 (crt.cpp:573-579).
 // (s0,s1) = Shoup pair of mhat^-1; (w, wp) = Shoup pair of psi_2^-1 * mhat^-1.
-template <int AR>
+template <int AR, bool WS = false>
 __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> wp, VT<AR> s0, VT<AR> s1, const QKT<AR>& k) {
   if constexpr (AR == 3) {
     const u32 s = X + Y;
@@ -254,8 +255,8 @@ __device__ __forceinline__ void bfly_inv_last(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT
   } else if constexpr (AR == 1) {
     const u64 s = add64(X, Y);
     const u64 d = add64u(X, k.q4) - Y;
-    X = shoup_acc(s, s0, s1, k.nq, 0);
-    Y = shoup_acc(d, w, wp, k.nq, 0);
+    X = shoup_acc<WS>(s, s0, s1, k.nq, 0);            // WS: the scale constants are wave-uniform
+    Y = shoup_acc<WS>(d, w, wp, k.nq, 0);
   } else {
     const u64 s = X + Y;
     const u64 d = X - Y + k.q2;
@@ -483,9 +484,11 @@ __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t,
     ++ordb;
     if (HALF >= 0 && ordb / (8 / LOLHIP_LEVEL_PARTS) != HALF) continue;
     const int s = level_tab<A, K>.slot[e];
-    if constexpr (!INV) bfly_fwd<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
-    else if constexpr (beta == 0) bfly_inv_last<AR>(v[e], v[e | (1 << K)], tw.l1w, tw.l1wp, tw.sc0, tw.sc1, qk);
-    else bfly_inv<AR>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+    // a wave holds one polynomial component (so per-component constants are wave-uniform) from n = 1024 up
+    constexpr bool WU = (A.ntb + R >= 10);
+    if constexpr (!INV) bfly_fwd<AR, WU && tw_uniform<A, K>()>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
+    else if constexpr (beta == 0) bfly_inv_last<AR, WU>(v[e], v[e | (1 << K)], tw.l1w, tw.l1wp, tw.sc0, tw.sc1, qk);
+    else bfly_inv<AR, WU && tw_uniform<A, K>()>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
   }
 }
 

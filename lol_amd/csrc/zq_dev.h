@@ -132,6 +132,10 @@ LH_D u64 csubn(u64 x, u64 negm) {
 //   Q = wp.hi*y.hi + hi32(wp.hi*y.lo) + hi32(wp.lo*y.hi)  in {floor(wp*y/2^64) - 2 .. same}
 // so (result - init) = w*y mod q + {0..3}*q  in [0, 4q) for any 64-bit y.  7 mads + 2
 // mul_hi instead of the 10 multiplies of the exact form; nq = -q (mod 2^64).
+// WS: the twiddle pair is wave-uniform (the scalar-loaded twiddles of the bottom levels, the scale
+// constants): its halves go into the multiplies as SGPR operands — every instruction below reads at most
+// one — instead of being copied to VGPRs first (450 v_mov per wave of the fused kernel).
+template <bool WS = false>
 LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
 #if LOLHIP_ASM_MAD == 4
   // One block, 9 v_mad_u64_u32.  The quotient's cross terms are summed EXACTLY:
@@ -167,24 +171,33 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
   // carry with s_nop; inside a block there is nothing to pad: VGPR RAW is interlocked).
   u64 Q, t, h;
   u32 ah, bh;
-  asm("v_mul_hi_u32 %1, %3, %5\n\t"
-      "v_mul_hi_u32 %2, %4, %6\n\t"
-      "v_mad_u64_u32 %0, vcc, %3, %6, 0\n\t"
-      "v_mad_u64_u32 %0, vcc, %1, 1, %0\n\t"
-      "v_mad_u64_u32 %0, vcc, %2, 1, %0"
-      : "=&v"(Q), "=&v"(ah), "=&v"(bh)
-      : "v"(hi32(wp)), "v"(lo32(wp)), "v"(lo32(y)), "v"(hi32(y))
-      : "vcc");
-  asm("v_mad_u64_u32 %0, vcc, %2, %4, %10\n\t"
-      "v_mad_u64_u32 %1, vcc, %2, %5, 0\n\t"
-      "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"
-      "v_mad_u64_u32 %1, vcc, %3, %4, %1\n\t"
-      "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"
-      "v_mad_u64_u32 %1, vcc, %7, %8, %1"
-      : "=&v"(t), "=&v"(h)
-      : "v"(lo32(w)), "v"(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),
-        "s"(lo32(nq)), "s"(hi32(nq)), "v"(init)      // nq: wave-uniform, one SGPR operand per mad
-      : "vcc");
+#define LH_SHOUP_BLOCKS(WC)                                                                          \
+  asm("v_mul_hi_u32 %1, %3, %5\n\t"                                                                  \
+      "v_mul_hi_u32 %2, %4, %6\n\t"                                                                  \
+      "v_mad_u64_u32 %0, vcc, %3, %6, 0\n\t"                                                         \
+      "v_mad_u64_u32 %0, vcc, %1, 1, %0\n\t"                                                         \
+      "v_mad_u64_u32 %0, vcc, %2, 1, %0"                                                             \
+      : "=&v"(Q), "=&v"(ah), "=&v"(bh)                                                               \
+      : WC(hi32(wp)), WC(lo32(wp)), "v"(lo32(y)), "v"(hi32(y))                                       \
+      : "vcc");                                                                                      \
+  asm("v_mad_u64_u32 %0, vcc, %2, %4, %10\n\t"                                                       \
+      "v_mad_u64_u32 %1, vcc, %2, %5, 0\n\t"                                                         \
+      "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"                                                        \
+      "v_mad_u64_u32 %1, vcc, %3, %4, %1\n\t"                                                        \
+      "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"                                                        \
+      "v_mad_u64_u32 %1, vcc, %7, %8, %1"                                                            \
+      : "=&v"(t), "=&v"(h)                                                                           \
+      : WC(lo32(w)), WC(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),            \
+        "s"(lo32(nq)), "s"(hi32(nq)), "v"(init)      /* nq: wave-uniform, one SGPR operand per mad */ \
+      : "vcc")
+#define LH_WC_V(x) "v"(x)
+#define LH_WC_S(x) "s"(x)
+  // Two asm blocks per product (hipcc pads every separate asm statement that writes an SGPR
+  // carry with s_nop; inside a block there is nothing to pad: VGPR RAW is interlocked).
+  if constexpr (WS) { LH_SHOUP_BLOCKS(LH_WC_S); } else { LH_SHOUP_BLOCKS(LH_WC_V); }
+#undef LH_SHOUP_BLOCKS
+#undef LH_WC_V
+#undef LH_WC_S
   u32 th = hi32(t) + lo32(h);
   asm("" : "+v"(th));          // keeps it ONE v_add_u32 (else: t + (h << 32) as v_mov + v_lshl_add_u64)
   return ((u64)th << 32) | lo32(t);
