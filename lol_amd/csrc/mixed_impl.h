@@ -146,19 +146,12 @@ __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const PT<CLS>* _
   }
 }
 
-// one d-vector of one stage, in place in LDS
+// the linear map of one stage on one d-vector in registers: o = A v
 template <int CLS, int D>
-__device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__ buf, int vec, int n, u64 n_magic,
-                                          const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
+__device__ __forceinline__ void apply_kind(const Stage& st, const MV<CLS> (&v)[D], MV<CLS> (&o)[D],
+                                           const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   const u64 q = mc.q;
-  const int rts = st.rts;
-  const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
-  const int x0 = blk * D * rts + r;
-  V* base = buf + x0;
-  V v[D], o[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
   // vectors of odd length p only occur in DFT_p stages; the L and G maps act on p-1 elements
   // (and small multipliers such as p-1-i are below q: the host sends moduli <= 16 elsewhere)
   switch ((D & 1) ? (int)ST_DFTP : st.kind) {
@@ -231,6 +224,21 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
 #pragma unroll
       for (int i = 0; i < D; ++i) o[i] = v[i];
   }
+}
+
+// one d-vector of one stage, in place in LDS
+template <int CLS, int D>
+__device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__ buf, int vec, int n, u64 n_magic,
+                                          const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
+  using V = MV<CLS>;
+  const int rts = st.rts;
+  const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
+  const int x0 = blk * D * rts + r;
+  V* base = buf + x0;
+  V v[D], o[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
+  apply_kind<CLS, D>(st, v, o, cst, mc);
   if (st.tw_off >= 0) {                  // the diagonal folded into this stage (crtTwiddle/dftTwiddle, mhat^-1, oddRad^-1)
     const int pi = mdiv(x0, n_magic);
     const int xi0 = x0 - pi * n;
@@ -242,6 +250,58 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
   }
 #pragma unroll
   for (int i = 0; i < D; ++i) base[i * rts] = o[i];
+}
+
+// FOUR adjacent d-vectors (positions r .. r+3 of one block) per thread, for stages whose stride is a
+// multiple of 4: the four share the index arithmetic, the matrix rows in SGPRs and — because the
+// diagonal's index is x / tw_div with tw_div a multiple of 4 (or the diagonal is a single constant) —
+// the twiddle of every row; LDS is accessed 16 bytes at a time.  Cuts the per-coefficient overhead of
+// the short dense vectors (d <= 7: the CRT_p / DFT_p stages of 3^e, 5^e, 7^e) of prime-power indices, where it
+// exceeds the arithmetic.  (The L and G maps stay one vector per thread.)
+template <int CLS, int D>
+__device__ __forceinline__ void stage_vec4(const Stage& st, MV<CLS>* __restrict__ buf, int vq, int n, u64 n_magic,
+                                           const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
+  using V = MV<CLS>;
+  constexpr int PER = 16 / (int)sizeof(V), NCH = 4 / PER;       // 16-byte chunks per 4 coefficients
+  typedef V VV __attribute__((ext_vector_type(PER)));
+  const int rts = st.rts, vec = vq * 4;
+  const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
+  const int x0 = blk * D * rts + r;
+  V* base = buf + x0;
+  V v[4][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const VV w = reinterpret_cast<const VV*>(base + i * rts)[c];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) v[c * PER + k][i] = w[k];
+    }
+  }
+  const PT<CLS>* M = cst + st.mat_off;          // dense kinds only (the dispatcher sends the L and G maps to stage_vec)
+  const bool has_tw = st.tw_off >= 0;
+  int xi0 = 0;
+  if (has_tw) { const int pi = mdiv(x0, n_magic); xi0 = x0 - pi * n; }
+  // row by row, each stored as soon as it is complete (every input is in registers already): 4 d + 4 live values
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    V o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o[w] = m_dot<CLS, D>(v[w], M + i * D, mc);
+    if (has_tw) {
+      const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
+      const PT<CLS> tw = cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o[w] = m_mul<CLS>(o[w], tw, mc);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      VV w;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) w[k] = o[c * PER + k];
+      reinterpret_cast<VV*>(base + i * rts)[c] = w;
+    }
+  }
 }
 
 // ST_POW2F / ST_POW2I: K levels of the 2-power factor on one 2^K-element register tile (plan.h).
@@ -364,14 +424,37 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       }
     } else {
       const int nvec = mdiv(tot, st.m_d);           // tot / d: exact, tot < 2^20
-      if constexpr (HOIST) {
+      // four adjacent vectors per thread where the stride allows it (stage_vec4)
+      // (class 2 only: in the classes with 128-bit accumulators the fourfold dot products multiply the code size
+      // and the compile time — 15 minutes for one translation unit — for kernels that are multiplier-bound anyway)
+      const bool wide4 = CLS == 2 && st.d <= 7 && (st.rts & 3) == 0 && (st.tw_off < 0 || (st.tw_div & 3) == 0 || st.tw_mod == 1) &&
+                         (st.kind == ST_DFTP || st.kind == ST_CRTP || st.kind == ST_CRTPINV);
+      bool done = false;
+      if constexpr (CLS == 2) if (wide4) {
+        done = true;
+        const int nq4 = nvec >> 2;                  // rts | n / d, so nvec is a multiple of 4 too
+#define LOLHIP_VECS4(X) X(2) X(3) X(4) X(5) X(6) X(7)
+        if constexpr (HOIST) {
+#define LOLHIP_X(D) case D: LOLHIP_LOOP(nq4, (stage_vec4<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
+          switch (st.d) { LOLHIP_VECS4(LOLHIP_X) default: break; }
+#undef LOLHIP_X
+        } else {
+#define LOLHIP_X(D) case D: stage_vec4<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
+          LOLHIP_LOOP(nq4, switch (st.d) { LOLHIP_VECS4(LOLHIP_X) default: break; })
+#undef LOLHIP_X
+        }
+#undef LOLHIP_VECS4
+      }
+      if (!done) {
+        if constexpr (HOIST) {
 #define LOLHIP_X(D) case D: LOLHIP_LOOP(nvec, (stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
-        switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }      // other lengths are excluded on the host (mixed_ok)
+          switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }      // other lengths are excluded on the host (mixed_ok)
 #undef LOLHIP_X
-      } else {
+        } else {
 #define LOLHIP_X(D) case D: stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
-        LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; })
+          LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; })
 #undef LOLHIP_X
+        }
       }
     }
     __syncthreads();
