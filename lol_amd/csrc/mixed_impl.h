@@ -258,17 +258,18 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
 // the twiddle of every row; LDS is accessed 16 bytes at a time.  Cuts the per-coefficient overhead of
 // the short dense vectors (d <= 7: the CRT_p / DFT_p stages of 3^e, 5^e, 7^e) of prime-power indices, where it
 // exceeds the arithmetic.  (The L and G maps stay one vector per thread.)
-template <int CLS, int D>
-__device__ __forceinline__ void stage_vec4(const Stage& st, MV<CLS>* __restrict__ buf, int vq, int n, u64 n_magic,
+template <int CLS, int D, int W>
+__device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict__ buf, int vq, int n, u64 n_magic,
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
-  constexpr int PER = 16 / (int)sizeof(V), NCH = 4 / PER;       // 16-byte chunks per 4 coefficients
+  constexpr int BYTES = W * (int)sizeof(V) < 16 ? W * (int)sizeof(V) : 16;
+  constexpr int PER = BYTES / (int)sizeof(V), NCH = W / PER;     // LDS chunks of up to 16 bytes per W coefficients
   typedef V VV __attribute__((ext_vector_type(PER)));
-  const int rts = st.rts, vec = vq * 4;
+  const int rts = st.rts, vec = vq * W;
   const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
   const int x0 = blk * D * rts + r;
   V* base = buf + x0;
-  V v[4][D];
+  V v[W][D];
 #pragma unroll
   for (int i = 0; i < D; ++i) {
 #pragma unroll
@@ -285,14 +286,14 @@ __device__ __forceinline__ void stage_vec4(const Stage& st, MV<CLS>* __restrict_
   // row by row, each stored as soon as it is complete (every input is in registers already): 4 d + 4 live values
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    V o[4];
+    V o[W];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) o[w] = m_dot<CLS, D>(v[w], M + i * D, mc);
+    for (int w = 0; w < W; ++w) o[w] = m_dot<CLS, D>(v[w], M + i * D, mc);
     if (has_tw) {
       const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
       const PT<CLS> tw = cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) o[w] = m_mul<CLS>(o[w], tw, mc);
+      for (int w = 0; w < W; ++w) o[w] = m_mul<CLS>(o[w], tw, mc);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -424,26 +425,29 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       }
     } else {
       const int nvec = mdiv(tot, st.m_d);           // tot / d: exact, tot < 2^20
-      // four adjacent vectors per thread where the stride allows it (stage_vec4)
+      // four (d <= 7) or two adjacent vectors per thread where the stride allows it (stage_vecw)
       // (class 2 only: in the classes with 128-bit accumulators the fourfold dot products multiply the code size
       // and the compile time — 15 minutes for one translation unit — for kernels that are multiplier-bound anyway)
-      const bool wide4 = CLS == 2 && st.d <= 7 && (st.rts & 3) == 0 && (st.tw_off < 0 || (st.tw_div & 3) == 0 || st.tw_mod == 1) &&
-                         (st.kind == ST_DFTP || st.kind == ST_CRTP || st.kind == ST_CRTPINV);
+      const bool dense = st.kind == ST_DFTP || st.kind == ST_CRTP || st.kind == ST_CRTPINV;
+      const int wd = st.d <= 7 ? 4 : 2;            // vectors per thread
+      // (two vectors per thread for d = 10..13 was tried: with the hoisted dispatch the 169-entry matrix and two
+      // vectors spill 184 VGPRs to scratch in the fused poly-mul)
+      const bool wide = CLS == 2 && dense && st.d <= 7 && (st.rts & (wd - 1)) == 0 && (st.tw_off < 0 || (st.tw_div & (wd - 1)) == 0 || st.tw_mod == 1);
       bool done = false;
-      if constexpr (CLS == 2) if (wide4) {
+      if constexpr (CLS == 2) if (wide) {
         done = true;
-        const int nq4 = nvec >> 2;                  // rts | n / d, so nvec is a multiple of 4 too
-#define LOLHIP_VECS4(X) X(2) X(3) X(4) X(5) X(6) X(7)
+        const int nqw = st.d <= 7 ? (nvec >> 2) : (nvec >> 1);      // rts | n / d, so nvec is a multiple of the width too
+#define LOLHIP_VECSW(X) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4) X(7, 4)
         if constexpr (HOIST) {
-#define LOLHIP_X(D) case D: LOLHIP_LOOP(nq4, (stage_vec4<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
-          switch (st.d) { LOLHIP_VECS4(LOLHIP_X) default: break; }
+#define LOLHIP_X(D, W) case D: LOLHIP_LOOP(nqw, (stage_vecw<CLS, D, W>(st, buf, it, n, n_magic, cst, mc))) break;
+          switch (st.d) { LOLHIP_VECSW(LOLHIP_X) default: break; }
 #undef LOLHIP_X
         } else {
-#define LOLHIP_X(D) case D: stage_vec4<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
-          LOLHIP_LOOP(nq4, switch (st.d) { LOLHIP_VECS4(LOLHIP_X) default: break; })
+#define LOLHIP_X(D, W) case D: stage_vecw<CLS, D, W>(st, buf, it, n, n_magic, cst, mc); break;
+          LOLHIP_LOOP(nqw, switch (st.d) { LOLHIP_VECSW(LOLHIP_X) default: break; })
 #undef LOLHIP_X
         }
-#undef LOLHIP_VECS4
+#undef LOLHIP_VECSW
       }
       if (!done) {
         if constexpr (HOIST) {

@@ -469,6 +469,9 @@ __device__ __forceinline__ void tw_fill_lds(V* dst, rsrc_t src, u32 comp, int n,
     }
   }
 }
+#ifndef LOLHIP_WS
+#define LOLHIP_WS 1      // wave-uniform twiddles as SGPR operands (A/B switch)
+#endif
 template <int AR, bool INV, Lay A, int K, int HALF = -1>
 __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t, const TwCtxT<VT<AR>>& tw, const QKT<AR>& qk) {
   constexpr int beta = A.reg[K];
@@ -485,7 +488,7 @@ __device__ __forceinline__ void level(VT<AR> (&v)[E], const LevelTwT<VT<AR>>& t,
     if (HALF >= 0 && ordb / (8 / LOLHIP_LEVEL_PARTS) != HALF) continue;
     const int s = level_tab<A, K>.slot[e];
     // a wave holds one polynomial component (so per-component constants are wave-uniform) from n = 1024 up
-    constexpr bool WU = (A.ntb + R >= 10);
+    constexpr bool WU = LOLHIP_WS && (A.ntb + R >= 10);
     if constexpr (!INV) bfly_fwd<AR, WU && tw_uniform<A, K>()>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
     else if constexpr (beta == 0) bfly_inv_last<AR, WU>(v[e], v[e | (1 << K)], tw.l1w, tw.l1wp, tw.sc0, tw.sc1, qk);
     else bfly_inv<AR, WU && tw_uniform<A, K>()>(v[e], v[e | (1 << K)], t.w[s], t.wp[s], qk);
