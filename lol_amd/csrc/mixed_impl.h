@@ -310,7 +310,8 @@ __device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict_
 // the butterfly of level s_lo + l on elements j, j | 2^l uses table entry (rts << l) + low + (j mod 2^l) * rts.
 // Canonical residues in and out of every butterfly (m_mul reduces fully), so the tiles compose with the
 // odd primes' stages in any order.  (Unreduced butterflies for q < 2^27 — 7 instead of 12 instructions — were
-// built and measured: both code paths in one function spill 66-99 VGPRs to scratch, crt of 64*9*25 0.18 -> 0.31 ms.)
+// built and measured twice: as a second path in this function they spill 66-99 VGPRs to scratch (crt of 64*9*25
+// 0.18 -> 0.31 ms); as separate instantiations they gain 0-5 % (2^11*7 crt 0.284 -> 0.269 ms) for +50 % build time.)
 template <int CLS, int K, bool INV>
 __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict__ buf, int tile,
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
