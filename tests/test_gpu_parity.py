@@ -661,6 +661,45 @@ def test_config3_she_ciphertext_product(gpu, cpuref):
     assert np.array_equal(e1[idx].cpu().numpy(), cpuref.gpow(R, s.astype(np.int64)))
 
 
+@pytest.mark.parametrize("m", [64 * 9 * 25, 128 * 7 * 13, 2 ** 11 * 7])
+def test_reference_index_shapes_full_batch(gpu, cpuref, m):
+    """The reference's own benchmark / tunnelling indices (Benchmarks/Default.hs:42-50; lol-apps Default.hs:49-56),
+    m = 2^e * odd through the one-launch route at a launch-filling batch: samples against the oracle, then the
+    size-independent properties over the whole batch (round trips, ring laws, aliasing), two moduli of different
+    classes in one tuple and a reference-sized single modulus."""
+    torch = pytest.importorskip("torch")
+    pps = lm.factor_pps(m)
+    for qs in ([lm.first_good_q(m, 2 ** 26)], [lm.first_good_q(m, 2 ** 24), lm.first_good_q(m, 2 ** 58)]):
+        P, R = gpu.Plan(pps, qs), Params(pps, qs)
+        B = 2048 // len(qs)
+        g = torch.Generator(device="cuda"); g.manual_seed(m)
+        rnd = lambda: torch.stack([torch.randint(0, q, (B, R.n), dtype=torch.int64, device="cuda", generator=g) for q in qs], dim=-1)
+        a, b = rnd(), rnd()
+        x = a.clone(); P.crt(x)
+        idx = [0, B // 2 - 1, B // 2, B - 1]
+        assert np.array_equal(x[idx].cpu().numpy(), cpuref.crt(R, a[idx].cpu().numpy()))
+        P.crtInv(x)
+        assert torch.equal(x, a)
+        for f, finv in ((P.l, P.lInv), (P.mulGPow, P.divGPow), (P.mulGDec, P.divGDec)):
+            x = a.clone(); f(x); finv(x)
+            assert torch.equal(x, a)
+        c = torch.empty_like(a)
+        P.polymul(a, b, out=c)
+        assert np.array_equal(c[idx].cpu().numpy(), cpuref.polymul(R, a[idx].cpu().numpy(), b[idx].cpu().numpy()).reshape(len(idx), R.n, len(qs)))
+        c2 = torch.empty_like(a)
+        P.polymul(b, a, out=c2)
+        assert torch.equal(c, c2)
+        one = torch.zeros_like(a); one[:, 0, :] = 1
+        P.polymul(a, one, out=c2)
+        assert torch.equal(c2, a)
+        x = a.clone(); P.polymul(x, b, out=x)
+        assert torch.equal(x, c)
+        # crtInv(crt a * crt b) op by op equals the fused launch
+        ah, bh = a.clone(), b.clone()
+        P.crt(ah); P.crt(bh); P.mul(ah, bh); P.crtInv(ah)
+        assert torch.equal(ah, c)
+
+
 def test_config4_mixed_radix_full_batch(gpu, cpuref):
     """m = 15015 = 3*5*7*11*13 (n = 5760), batch 1024, q just above 2^60 and 2^30"""
     torch = pytest.importorskip("torch")
