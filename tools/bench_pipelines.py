@@ -65,8 +65,11 @@ def main():
     report("ctmul_crt_op_by_op", f"m=2^15 T=4 59-bit B={B}", ms_u, B, 7 * slab)
     del ops, outs
     # ---- config 5: key switch, m' = 2048, q = (1017857, 1032193), TrivGad; and at n = 8192 -----
-    for lm_, qs5, B in ((11, [1017857, 1032193], 8192), (14, good_qs(2 ** 14, 2 ** 20, 2), 1024)):
-        P = lol_amd.Plan([(2, lm_)], qs5)
+    # (pps, moduli, batch): config 5's ring; the same at n = 8192; the reference's non-2-power key-switch benchmark
+    # F64*F9*F25 with Zq (1008001 ** 1065601) (lol-apps Benchmarks/Default.hs:49)
+    for pps5, qs5, B in (([(2, 11)], [1017857, 1032193], 8192), ([(2, 14)], good_qs(2 ** 14, 2 ** 20, 2), 1024),
+                         ([(2, 6), (3, 2), (5, 2)], [1008001, 1065601], 2048)):
+        P = lol_amd.Plan(pps5, qs5)
         for base in (0, 256):
             Ld = P.decomposeLen(base)
             c2 = rnd(gen, qs5, B, P.n)
@@ -76,7 +79,7 @@ def main():
             out = torch.empty_like(add)
             slab = B * P.n * P.T * 8
             ms = timeit(lambda: L.lolhip_keyswitch_batch(P._h, st, ptr(c2), base, ptr(hint), 2, ptr(add), ptr(out), ptr(work), B))
-            report("keyswitch", f"m=2^{lm_} T=2 q~2^20 base={base} L={Ld} B={B}", ms, B, 5 * slab)
+            report("keyswitch", f"m={P.m} T=2 q~2^20 base={base} L={Ld} B={B}", ms, B, 5 * slab)
             ms = timeit(lambda: L.lolhip_decompose_batch(P._h, st, ptr(c2), base, ptr(work), B))
             report("  decompose", f"L={Ld}", ms, B, (1 + Ld) * slab)
             ms = timeit(lambda: L.lolhip_crt_batch(P._h, st, ptr(work), Ld * B))
