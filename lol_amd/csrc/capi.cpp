@@ -83,6 +83,11 @@ bool use_mixed(const Plan& P, const StageProgram& sp) {
   return !scalar_only && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
 }
 
+bool q_below(const Plan& P, int bits) {
+  for (u64 q : P.qs) if (q >> bits) return false;
+  return true;
+}
+
 // m = 2^e * odd in one launch of the vector interpreter (plan.h: prog_crt_fused)
 bool use_fused2(const Plan& P) {
   const bool off = getenv("LOLHIP_NO_FUSED2") != nullptr;                            // A/B switch (read per call: tests flip it)
@@ -422,7 +427,7 @@ int lolhip_knapsack_batch(const lolhip_plan* p, void* stream, const int64_t* xs_
   int rc = need_device(p); if (rc) return rc;
   if (L < 0 || K < 1 || K > 3 || B < 0) return LOLHIP_ERR_INVALID;
   if (B > 0 && (!out || (L > 0 && (!xs_crt || !hint)))) return LOLHIP_ERR_INVALID;
-  return launch_knapsack((hipStream_t)stream, xs_crt, L, hint, K, addend, out, B, p->P.n, p->P.T, p->P.d_mod)
+  return launch_knapsack((hipStream_t)stream, xs_crt, L, hint, K, addend, out, B, p->P.n, p->P.T, p->P.d_mod, q_below(p->P, 29))
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
@@ -454,7 +459,7 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
   if (launch_decompose(stream, c2_pow, work, B, P.n, d, P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
   rc = do_crt(P, stream, work, (int64_t)d.L * B, false);                 // all L*B digit polynomials in one launch
   if (rc) return rc;
-  return launch_knapsack(stream, work, d.L, hint, K, addend, out, B, P.n, P.T, P.d_mod) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+  return launch_knapsack(stream, work, d.L, hint, K, addend, out, B, P.n, P.T, P.d_mod, q_below(P, 29)) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 }  // namespace
 
@@ -586,7 +591,7 @@ int lolhip_evallin_batch(const lolhip_ext* x_er, const lolhip_ext* x_es, void* s
   if (!rc) rc = run_prog(*PS, PS->prog_l, (hipStream_t)s, tmp_s, rel * B);                 // Dec -> Pow
   if (!rc) rc = do_crt(*PS, (hipStream_t)s, tmp_s, rel * B, false);
   if (rc) return rc;
-  return launch_knapsack((hipStream_t)s, tmp_s, (int)rel, ys_crt, 1, nullptr, out, B, PS->n, PS->T, PS->d_mod)
+  return launch_knapsack((hipStream_t)s, tmp_s, (int)rel, ys_crt, 1, nullptr, out, B, PS->n, PS->T, PS->d_mod, q_below(*PS, 29))
                  == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 int64_t lolhip_tunnel_work_len(const lolhip_ext* x_er, const lolhip_ext* x_es, int64_t base, int64_t B) {

@@ -27,7 +27,7 @@ hipError_t launch_ctmul(hipStream_t s, const i64* c0, const i64* c1, const i64* 
 hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64 n, const DecompParams& p,
                             const ModCtx* mod);
 hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint, int K, const i64* addend, i64* out,
-                           i64 B, i64 n, int T, const ModCtx* mod);
+                           i64 B, i64 n, int T, const ModCtx* mod, bool q32 = false);   // q32: every modulus below 2^29 (64-bit accumulators)
 hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, const RescaleParams& p,
                           const ModCtx* mod);
 

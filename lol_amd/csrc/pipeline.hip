@@ -13,6 +13,8 @@
 // three mulG for a ciphertext product: 21 slab passes) is one pass here (4 reads, 3 writes).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pipeline.h"
 #include "zq_dev.h"
 
@@ -140,7 +142,10 @@ hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64
 // ---------------------------------------------------------------------------------------
 // knapsack
 // ---------------------------------------------------------------------------------------
-template <int K>
+// Q32: every modulus below 2^29 (the reference's own): products are below 2^58, 32 of them fit one 64-bit
+// accumulator — one v_mad_u64_u32 per term and a single-word Barrett step at the end instead of 128-bit sums
+// and a two-step division.
+template <int K, bool Q32>
 __global__ void __launch_bounds__(256)
 k_knapsack(const i64* __restrict__ xs, int L, const i64* __restrict__ hint, const i64* addend, i64* out, i64 total,
            u32 per, int T, const ModCtx* __restrict__ mod) {
@@ -154,24 +159,34 @@ k_knapsack(const i64* __restrict__ xs, int L, const i64* __restrict__ hint, cons
     u32 r = r_s + l;
     if (r >= per) r %= per;
     const ModCtx mc = mod[r % (u32)T];
-    u128 acc[K];
+    using Acc = std::conditional_t<Q32, u64, u128>;
+    Acc acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0;
+    auto fold = [&](Acc a) -> u64 {
+      if constexpr (Q32) {
+        const u64 rr = (u64)a - __umul64hi((u64)a, mc.mu) * mc.q;       // [0, 2q)
+        return rr >= mc.q ? rr - mc.q : rr;
+      } else {
+        return reduce128((u64)((u128)a >> 64), (u64)a, mc);
+      }
+    };
     for (int j = 0; j < L; ++j) {
       const u64 x = canon_in(xs[(i64)j * total + g], mc.q);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const u64 h = canon_in(hint[((i64)j * K + k) * per + r], mc.q);
-        acc[k] += (u128)x * h;                                   // each term < q^2 < 2^124
+        if constexpr (Q32) acc[k] += (u64)(u32)x * (u32)h;           // < 2^58
+        else acc[k] += (u128)x * h;                                  // each term < q^2 < 2^124
       }
-      if ((j & 7) == 7) {                                        // keep the sum below 2^128
+      if ((j & (Q32 ? 31 : 7)) == (Q32 ? 31 : 7)) {                  // keep the sum inside the accumulator
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = reduce128((u64)(acc[k] >> 64), (u64)acc[k], mc);
+        for (int k = 0; k < K; ++k) acc[k] = fold(acc[k]);
       }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      u64 v = reduce128((u64)(acc[k] >> 64), (u64)acc[k], mc);
+      u64 v = fold(acc[k]);
       if (addend) v = addmod(v, canon_in(addend[(i64)k * total + g], mc.q), mc.q);
       out[(i64)k * total + g] = (i64)v;
     }
@@ -179,19 +194,24 @@ k_knapsack(const i64* __restrict__ xs, int L, const i64* __restrict__ hint, cons
 }
 
 hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint, int K, const i64* addend, i64* out,
-                           i64 B, i64 n, int T, const ModCtx* mod) {
+                           i64 B, i64 n, int T, const ModCtx* mod, bool q32) {
   const i64 total = B * n * T;
   if (total == 0) return hipSuccess;
   unsigned blocks;
   if (!tiles_for(total, &blocks)) return hipErrorInvalidValue;
   const dim3 grid(blocks), block(256);
   const u32 per = (u32)(n * T);
-  switch (K) {
-    case 1: hipLaunchKernelGGL(k_knapsack<1>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
-    case 2: hipLaunchKernelGGL(k_knapsack<2>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
-    case 3: hipLaunchKernelGGL(k_knapsack<3>, grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod); break;
+#define LOLHIP_KS(KK, QQ) hipLaunchKernelGGL((k_knapsack<KK, QQ>), grid, block, 0, s, xs, L, hint, addend, out, total, per, T, mod)
+  switch (K * 2 + (q32 ? 1 : 0)) {
+    case 2: LOLHIP_KS(1, false); break;
+    case 3: LOLHIP_KS(1, true); break;
+    case 4: LOLHIP_KS(2, false); break;
+    case 5: LOLHIP_KS(2, true); break;
+    case 6: LOLHIP_KS(3, false); break;
+    case 7: LOLHIP_KS(3, true); break;
     default: return hipErrorInvalidValue;
   }
+#undef LOLHIP_KS
   return hipGetLastError();
 }
 
