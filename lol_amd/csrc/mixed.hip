@@ -4,11 +4,10 @@
 
 namespace lolhip {
 
-template <int CLS> hipError_t launch_mixed_cls(const MixedLaunch& a);
-extern template hipError_t launch_mixed_cls<0>(const MixedLaunch&);
-extern template hipError_t launch_mixed_cls<1>(const MixedLaunch&);
-extern template hipError_t launch_mixed_cls<2>(const MixedLaunch&);
-extern template hipError_t launch_mixed_cls<3>(const MixedLaunch&);
+template <int CLS, int MODE> hipError_t launch_cls(const MixedLaunch& a);     // MODE 0: one program, 2: fused poly-mul
+#define LOLHIP_EXT(C) extern template hipError_t launch_cls<C, 0>(const MixedLaunch&); extern template hipError_t launch_cls<C, 2>(const MixedLaunch&);
+LOLHIP_EXT(0) LOLHIP_EXT(1) LOLHIP_EXT(2) LOLHIP_EXT(3)
+#undef LOLHIP_EXT
 
 bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T) {
   if (n > 8192) return false;
@@ -26,11 +25,12 @@ bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T
 hipError_t launch_mixed(const MixedLaunch& a) {
   if (a.B == 0) return hipSuccess;
   switch (a.cls) {
-    case 0: return launch_mixed_cls<0>(a);
-    case 1: return launch_mixed_cls<1>(a);
-    case 3: return launch_mixed_cls<3>(a);
-    default: return launch_mixed_cls<2>(a);
+    case 0: return a.fused ? launch_cls<0, 2>(a) : launch_cls<0, 0>(a);
+    case 1: return a.fused ? launch_cls<1, 2>(a) : launch_cls<1, 0>(a);
+    case 3: return a.fused ? launch_cls<3, 2>(a) : launch_cls<3, 0>(a);
+    default: return a.fused ? launch_cls<2, 2>(a) : launch_cls<2, 0>(a);
   }
+
 }
 
 }  // namespace lolhip

@@ -1,5 +1,5 @@
-// lol_amd/csrc/mixed_cls0.hip — the mixed-radix kernels of arithmetic/storage class 0 (see mixed_impl.h)
+// lol_amd/csrc/mixed_cls0.hip — the mixed-radix kernels of arithmetic/storage class 0, single program (see mixed_impl.h)
 #include "mixed_impl.h"
 namespace lolhip {
-template hipError_t launch_mixed_cls<0>(const MixedLaunch&);
+template hipError_t launch_cls<0, 0>(const MixedLaunch&);
 }  // namespace lolhip

@@ -489,6 +489,9 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
         const u64* __restrict__ consts64, const u32* __restrict__ consts32, int cpc, const ModCtx* __restrict__ mod) {
   using V = MV<CLS>;
+  // hoisted dispatch (run_stages): the fused poly-mul of the 32-bit classes only — in the 64-bit classes it measured
+  // no gain (m = 15015, 61 bits: 0.324 vs 0.320 ms)
+  constexpr bool HOISTED = (MODE == 2 && !wide<CLS>()) || LOLHIP_MIXED_HOIST0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V* buf = reinterpret_cast<V*>(smem);
   const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
@@ -535,7 +538,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
     if constexpr (MODE == 0) {
       to_lds(ra);
       __syncthreads();
-      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       store16();
     } else {
       const bool square = (a_in == b_in);
@@ -544,7 +547,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
       if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       __syncthreads();
-      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       V ah[KMAX];                        // a-hat: every thread keeps the positions it owns
       {
         const int x0 = fresh(tid);
@@ -555,7 +558,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         __syncthreads();                 // every a-hat coefficient is in registers before b overwrites the buffer
         to_lds(ra);
         __syncthreads();
-        run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+        run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       }
       {
         const int x0 = fresh(tid);
@@ -563,7 +566,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
       }
       __syncthreads();
-      run_stages<CLS, MODE == 2 || LOLHIP_MIXED_HOIST0>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
+      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
       store16();
     }
     __syncthreads();                     // the buffer is reused by the next item
@@ -590,11 +593,6 @@ hipError_t launch_cls(const MixedLaunch& a) {
   else LOLHIP_MIXED_LAUNCH(16);
 #undef LOLHIP_MIXED_LAUNCH
   return hipGetLastError();
-}
-
-template <int CLS>
-hipError_t launch_mixed_cls(const MixedLaunch& a) {
-  return a.fused ? launch_cls<CLS, 2>(a) : launch_cls<CLS, 0>(a);
 }
 
 }  // namespace lolhip
