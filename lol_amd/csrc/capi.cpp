@@ -418,7 +418,7 @@ int lolhip_decompose_batch(const lolhip_plan* p, void* stream, const int64_t* c_
   DecompParams d;
   rc = make_decomp(p->P, base, d); if (rc) return rc;
   if (B < 0 || (B > 0 && (!c_pow || !digits))) return LOLHIP_ERR_INVALID;
-  return launch_decompose((hipStream_t)stream, c_pow, digits, B, p->P.n, d, p->P.d_mod) == hipSuccess
+  return launch_decompose((hipStream_t)stream, c_pow, digits, B, p->P.n, d, p->P.d_mod, q_below(p->P, 31)) == hipSuccess
              ? LOLHIP_OK : LOLHIP_ERR_HIP;
 }
 
@@ -456,7 +456,7 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
     }
     return launch_keyswitch_fused(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
-  if (launch_decompose(stream, c2_pow, work, B, P.n, d, P.d_mod) != hipSuccess) return LOLHIP_ERR_HIP;
+  if (launch_decompose(stream, c2_pow, work, B, P.n, d, P.d_mod, q_below(P, 31)) != hipSuccess) return LOLHIP_ERR_HIP;
   rc = do_crt(P, stream, work, (int64_t)d.L * B, false);                 // all L*B digit polynomials in one launch
   if (rc) return rc;
   return launch_knapsack(stream, work, d.L, hint, K, addend, out, B, P.n, P.T, P.d_mod, q_below(P, 29)) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;

@@ -25,7 +25,7 @@ struct RescaleParams {
 hipError_t launch_ctmul(hipStream_t s, const i64* c0, const i64* c1, const i64* d0, const i64* d1, i64* e0, i64* e1,
                         i64* e2, const i64* gcrt, i64 B, i64 n, int T, const ModCtx* mod);
 hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64 n, const DecompParams& p,
-                            const ModCtx* mod);
+                            const ModCtx* mod, bool q32 = false);   // q32: every modulus below 2^31
 hipError_t launch_knapsack(hipStream_t s, const i64* xs, int L, const i64* hint, int K, const i64* addend, i64* out,
                            i64 B, i64 n, int T, const ModCtx* mod, bool q32 = false);   // q32: every modulus below 2^29 (64-bit accumulators)
 hipError_t launch_rescale(hipStream_t s, const i64* c, i64* out, i64 B, i64 n, const RescaleParams& p,

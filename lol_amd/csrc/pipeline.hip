@@ -93,24 +93,44 @@ __device__ __forceinline__ u64 reduce_signed(i64 d, const ModCtx& mc) {
   return (d < 0 && r != 0) ? mc.q - r : r;
 }
 
+// One thread per ROW (coefficient): the T components are lifted and their digits extracted once, every
+// digit is reduced into the T target components and stored as one contiguous T-word chunk, so a wave
+// writes 64 * T consecutive words per digit.  (The first version ran one thread per output column: every
+// digit was extracted T times and a store instruction covered only every T-th word.)
+// Q32: every modulus below 2^31 and base <= 2^31: digits fit 31 bits, one-word Barrett reduction.
+// V2: T = 2 and a 16-byte aligned digit slab: the pair goes out as one 16-byte store.
+typedef u64 dec_u64x2 __attribute__((ext_vector_type(2)));
+template <bool Q32, bool V2>
 __global__ void __launch_bounds__(256)
 k_decompose(const i64* __restrict__ c, i64* __restrict__ digits, i64 rows, DecompParams p,
             const ModCtx* __restrict__ mod) {
-  const int T = p.T;
-  const i64 total = rows * T;              // one thread per output column (row r, component s)
+  const int T = V2 ? 2 : p.T;
   const i64 shift = p.base / 2;
   const i64 s0 = (i64)blockIdx.x * TILE;                      // wave-uniform
-  const i64 row_s = s0 / T;
-  const u32 t_s = (u32)(s0 - row_s * T);
+  auto red = [&](i64 d, int s) -> u64 {
+    if constexpr (Q32) {
+      const u32 q = (u32)mod[s].q, mu = (u32)(mod[s].mu >> 32);
+      const u32 ad = d >= 0 ? (u32)d : (u32)(-d);
+      u32 x = ad - __umulhi(ad, mu) * q;                      // [0, 2q)
+      x = min(x, x - q);
+      return (u64)((d < 0 && x != 0) ? q - x : x);
+    } else {
+      return reduce_signed(d, mod[s]);
+    }
+  };
+  auto put = [&](i64 j, i64 r, i64 d) {                       // digit j of row r: reduced into every component
+    i64* o = digits + (j * rows + r) * T;
+    if constexpr (V2) {
+      dec_u64x2 w; w.x = red(d, 0); w.y = red(d, 1);
+      *reinterpret_cast<dec_u64x2*>(o) = w;
+    } else {
+      for (int s = 0; s < T; ++s) o[s] = (i64)red(d, s);
+    }
+  };
 #pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const u32 l = (u32)k * 256u + threadIdx.x;
-    const i64 g = s0 + l;
-    if (g >= total) continue;
-    const u32 dr = (t_s + l) / (u32)T;
-    const i64 r = row_s + dr;
-    const int s = (int)(t_s + l - dr * (u32)T);
-    const ModCtx ms = mod[s];
+  for (int e = 0; e < EPT; ++e) {
+    const i64 r = s0 + (u32)e * 256u + threadIdx.x;
+    if (r >= rows) continue;
     i64 j = 0;
     for (int t = 0; t < T; ++t) {
       const u64 qt = mod[t].q;
@@ -121,21 +141,26 @@ k_decompose(const i64* __restrict__ c, i64* __restrict__ digits, i64 rows, Decom
         const i64 qd = floor_div(a, p);
         const i64 rem = a - qd * p.base - shift;
         v = qd;
-        digits[(j * rows + r) * T + s] = (i64)reduce_signed(rem, ms);
+        put(j, r, rem);
       }
-      digits[(j * rows + r) * T + s] = (i64)reduce_signed(v, ms);  // last digit: what is left
+      put(j, r, v);                                              // last digit: what is left
       ++j;
     }
   }
 }
 
 hipError_t launch_decompose(hipStream_t s, const i64* c, i64* digits, i64 B, i64 n, const DecompParams& p,
-                            const ModCtx* mod) {
+                            const ModCtx* mod, bool q32) {
   const i64 rows = B * n;
   if (rows == 0) return hipSuccess;
   unsigned blocks;
-  if (!tiles_for(rows * p.T, &blocks)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_decompose, dim3(blocks), dim3(256), 0, s, c, digits, rows, p, mod);
+  if (!tiles_for(rows, &blocks)) return hipErrorInvalidValue;
+  const bool fast = q32 && p.base <= ((i64)1 << 31);
+  const bool v2 = p.T == 2 && (((uintptr_t)digits) & 15) == 0;
+#define LOLHIP_DEC(QQ, VV) hipLaunchKernelGGL((k_decompose<QQ, VV>), dim3(blocks), dim3(256), 0, s, c, digits, rows, p, mod)
+  if (fast) { if (v2) LOLHIP_DEC(true, true); else LOLHIP_DEC(true, false); }
+  else { if (v2) LOLHIP_DEC(false, true); else LOLHIP_DEC(false, false); }
+#undef LOLHIP_DEC
   return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ hipError_t launch_pointwise_mul(hipStream_t, i64*, const i64*, i64, i64, int, co
 hipError_t launch_gather(hipStream_t, i64*, const i64*, const int32_t*, i64, i64, i64, int, const ModCtx*, bool) { return hipErrorNoDevice; }
 hipError_t launch_twace_crt(hipStream_t, i64*, const i64*, const int32_t*, const i64*, i64, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
 hipError_t launch_ctmul(hipStream_t, const i64*, const i64*, const i64*, const i64*, i64*, i64*, i64*, const i64*, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
-hipError_t launch_decompose(hipStream_t, const i64*, i64*, i64, i64, const DecompParams&, const ModCtx*) { return hipErrorNoDevice; }
+hipError_t launch_decompose(hipStream_t, const i64*, i64*, i64, i64, const DecompParams&, const ModCtx*, bool) { return hipErrorNoDevice; }
 hipError_t launch_knapsack(hipStream_t, const i64*, int, const i64*, int, const i64*, i64*, i64, i64, int, const ModCtx*, bool) { return hipErrorNoDevice; }
 hipError_t launch_rescale(hipStream_t, const i64*, i64*, i64, i64, const RescaleParams&, const ModCtx*) { return hipErrorNoDevice; }
 hipError_t launch_coeffs(hipStream_t, i64*, const i64*, const int32_t*, i64, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
