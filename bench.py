@@ -7,8 +7,12 @@ operands and results in the powerful basis, resident in HBM.  One step = one fus
 poly-mul launch over the whole batch (c = crtInv(crt a * crt b)).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); the
-batch dimension shards with no data-path collective (every polynomial is independent),
+N > 1 runs one rank per GPU.  Either the caller starts the ranks (torch.distributed.run sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; WORLD_SIZE must then equal --gpus), or — plain
+`python bench.py --gpus N` with no WORLD_SIZE in the environment — this process starts N fresh
+child ranks itself BEFORE anything touches the GPU (launch_ranks below: the parent never
+initialises HIP and never re-execs), relays rank 0's JSON line and exits non-zero if any rank fails.
+The batch dimension shards with no data-path collective (every polynomial is independent),
 so scaling is weak: each rank multiplies its own 4096-polynomial shard.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` is algorithmic bytes
@@ -299,6 +303,104 @@ def dropin_c1():
     return res
 
 
+def timed_steps(step, steps, dist, sync, device, before=None, after=None):
+    """The contract's timed region: barrier + device sync on both sides of EXACTLY `steps` steps,
+    MAX over ranks of the local wall time.  `dist` is torch.distributed or None (one rank)."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    if before:
+        before()
+    for _ in range(steps):
+        step()
+    if after:
+        after()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def launcher_selftest(args, rank, world):
+    """CPU-only: the rank start-up, rendezvous, barrier/MAX timing and rank-0 reporting of the N > 1
+    path on gloo, with a step that launches nothing.  tests/test_dist.py runs it at N = 2."""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lol_amd.dist import shard_range
+    lo, hi = shard_range(args.batch * world, rank, world)       # weak scaling: every rank owns args.batch items
+    acc = [0]
+
+    def step():
+        acc[0] += hi - lo
+    for _ in range(args.warmup):
+        step()
+    acc[0] = 0
+    elapsed = timed_steps(step, args.steps, dist, lambda: None, "cpu")
+    total = torch.tensor([acc[0]], dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(total)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest (no kernel launched; NOT a measurement)", "value": None,
+                          "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+                          "backend": dist.get_backend() if dist else None, "steps": args.steps, "warmup": args.warmup,
+                          "items_all_ranks": int(total.item()), "elapsed_s": round(elapsed, 6)}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def launch_ranks(argv, n, timeout_s=None):
+    """Start n child ranks of this script (fresh interpreters; RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment), wait for all of them, relay rank 0's stdout.  Runs before any
+    GPU call: the parent only waits.  Returns the exit code for the whole job."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    t_end = None if timeout_s is None else time.time() + timeout_s
+    out0, codes = b"", [None] * n
+    try:
+        out0 = procs[0].communicate(timeout=timeout_s)[0]
+        codes[0] = procs[0].returncode
+        for r in range(1, n):
+            left = None if t_end is None else max(1.0, t_end - time.time())
+            codes[r] = procs[r].wait(timeout=left)
+    except subprocess.TimeoutExpired:
+        pass
+    finally:
+        for pr in procs:            # exactly the children started above, by PID
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench: ranks failed or timed out (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,24 +410,44 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--clock-warmup-s", type=float, default=0.4)
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU-only check of the rank launcher and the rendezvous/timing protocol (gloo, no kernel): "
+                         "prints a line whose metric says so; never a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         "(or leave WORLD_SIZE unset and let bench.py start them)")
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
 
     import numpy as np
     import torch
 
     import lol_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (liblolhip has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench: rank {rank} wants cuda:{local_rank} but the node exposes {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench: process group size differs from --gpus")
     n_gpus = world
 
     q = lol_amd.good_q(M_INDEX, Q_LOWER)
@@ -353,22 +475,8 @@ def main():
     # one HIP-event pair on the launch stream around the K launches (they queue back to back;
     # an event pair per launch would put a marker packet between every two kernels)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda",
+                          before=lambda: ev0.record(stream), after=lambda: ev1.record(stream))
     kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps)
 
     # ---- N > 1: the one optional collective, all-gather of the result shards ----
@@ -394,7 +502,8 @@ def main():
     if rank == 0:
         from oracle.oracle import CpuRef, Params
         ref = Params([(2, 14)], [q])
-        idx = list(range(0, B, max(1, B // 4)))[:4]
+        # first and last polynomial of every dispatch round (1024 workgroups resident at a time), both sides
+        idx = sorted({i for i in (0, 1023, 1024, 2047, 2048, 3071, 3072, B - 1, B // 2) if 0 <= i < B})
         want = CpuRef().polymul(ref, a[idx].cpu().numpy(), b[idx].cpu().numpy())
         parity = bool(np.array_equal(c[idx].cpu().numpy(), want.reshape(len(idx), n, T)))
         if not parity:
@@ -416,6 +525,8 @@ def main():
             "value": round(value, 1),
             "unit": "poly-muls/s",
             "n_gpus": n_gpus,
+            "world_size": dist.get_world_size() if dist is not None else 1,
+            "backend": (backend + " (RCCL)") if backend == "nccl" else backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

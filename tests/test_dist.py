@@ -47,3 +47,43 @@ def test_allgather_two_ranks_gloo(tmp_path, batch):
     mp.spawn(_worker, args=(2, port, batch, 4, 2, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert bool(np.load(tmp_path / f"ok{r}.npy")[0])
+
+
+def _run_bench(*argv, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py itself starts two ranks, they rendezvous
+    (gloo here), run the barrier / MAX-over-ranks protocol and rank 0 reports n_gpus = 2."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--launcher-selftest")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["backend"] == "gloo"
+    assert out["items_all_ranks"] == 2 * 16 * 3  # both ranks did their own shard, every step
+    assert "NOT a measurement" in out["metric"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _run_bench("--gpus", "2", "--launcher-selftest", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_fails_when_any_rank_fails():
+    """No GPU here: every real rank exits non-zero, and so must the launcher (no JSON line)."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present: the real ranks would run")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "ranks failed" in r.stderr
