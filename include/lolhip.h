@@ -310,6 +310,17 @@ LOLHIP_API int64_t lolhip_tunnelhint_read(const uint8_t *buf, int64_t len, uint3
                                           int64_t *func_off, int64_t *func_len, int64_t *hint_off, int64_t *hint_len,
                                           int cap_hints);
 
+/* Measurement aid: device-to-device copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) with
+ * 16 bytes per lane — the read-once/write-once ceiling bench.py quotes beside every HBM-bound leg.
+ * variant 0: one tile per workgroup; 1: persistent workgroups. */
+LOLHIP_API int lolhip_copy_slab(void *stream, void *dst, const void *src, int64_t bytes, int variant);
+
+/* Test and A/B aid, not part of the drop-in surface: force a launch path.  `name` is one of
+ * GENERIC_SCALAR, NO_FUSED2, NO_POW2_PART, POLYMUL_UNFUSED, KEYSWITCH_UNFUSED, NO_T1, NO_PIPE (each is
+ * also read ONCE at first use from the environment variable LOLHIP_<name>); value 0 restores the
+ * default path.  Every path computes the same residues.  Returns LOLHIP_OK or LOLHIP_ERR_INVALID. */
+LOLHIP_API int lolhip_debug_set(const char *name, int value);
+
 /* number of HIP devices visible (0 without a GPU); never initialises a context */
 LOLHIP_API int lolhip_device_count(void);
 LOLHIP_API const char *lolhip_version(void);

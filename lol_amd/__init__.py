@@ -9,11 +9,11 @@ There is no CPU fallback: without the built library, or without a GPU, compute
 calls raise.
 """
 from .tensor import (  # noqa: F401
-    LolHipError, NoDeviceError, Plan, Ext, lib, lib_path, device_count, good_q, factor_pps,
+    LolHipError, NoDeviceError, Plan, Ext, lib, lib_path, device_count, debug_set, good_q, factor_pps,
     rqproduct_read, rqproduct_write, kshint_read, kshint_write, r_read, secretkey_read, kqproduct_read,
     linearrq_read, tunnelhint_read,
 )
 
-__all__ = ["LolHipError", "NoDeviceError", "Plan", "Ext", "lib", "lib_path", "device_count",
+__all__ = ["LolHipError", "NoDeviceError", "Plan", "Ext", "lib", "lib_path", "device_count", "debug_set",
            "good_q", "factor_pps", "rqproduct_read", "rqproduct_write", "kshint_read", "kshint_write", "r_read",
            "secretkey_read", "kqproduct_read", "linearrq_read", "tunnelhint_read"]

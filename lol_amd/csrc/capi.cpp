@@ -5,11 +5,13 @@
 // entry point needs a HIP device and says so when there is none.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -18,6 +20,28 @@
 #include "plan.h"
 
 using namespace lolhip;
+
+// ---- A/B switches (plan.h): one atomic per switch, seeded once from LOLHIP_<NAME> ------------
+namespace lolhip {
+namespace {
+const char* const kSwitchNames[SW_COUNT] = {"GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED",
+                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE"};
+std::atomic<int> g_switch[SW_COUNT];
+std::once_flag g_switch_once;
+void switches_init() {
+  std::call_once(g_switch_once, [] {
+    for (int i = 0; i < SW_COUNT; ++i) {
+      const std::string name = std::string("LOLHIP_") + kSwitchNames[i];
+      g_switch[i].store(getenv(name.c_str()) != nullptr ? 1 : 0, std::memory_order_relaxed);
+    }
+  });
+}
+}  // namespace
+bool sw(Switch which) {
+  switches_init();
+  return g_switch[which].load(std::memory_order_relaxed) != 0;
+}
+}  // namespace lolhip
 
 struct lolhip_plan { Plan P; };
 struct lolhip_ext { ExtPlan X; };
@@ -79,8 +103,7 @@ struct StreamBuf {
 };
 
 bool use_mixed(const Plan& P, const StageProgram& sp) {
-  static const bool scalar_only = getenv("LOLHIP_GENERIC_SCALAR") != nullptr;       // A/B switch
-  return !scalar_only && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
+  return !sw(SW_GENERIC_SCALAR) && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
 }
 
 bool q_below(const Plan& P, int bits) {
@@ -90,8 +113,7 @@ bool q_below(const Plan& P, int bits) {
 
 // m = 2^e * odd in one launch of the vector interpreter (plan.h: prog_crt_fused)
 bool use_fused2(const Plan& P) {
-  const bool off = getenv("LOLHIP_NO_FUSED2") != nullptr;                            // A/B switch (read per call: tests flip it)
-  return !off && P.fused2 && use_mixed(P, P.prog_crt_fused) && use_mixed(P, P.prog_crtinv_fused);
+  return !sw(SW_NO_FUSED2) && P.fused2 && use_mixed(P, P.prog_crt_fused) && use_mixed(P, P.prog_crtinv_fused);
 }
 
 // y = program(src or y) over B polynomials
@@ -147,7 +169,7 @@ int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
   // (measured at 58 bits: m = 11648 0.62 vs 0.55 ms, m = 14336 0.65 vs 0.52 ms; at 26 bits fused wins everywhere)
   const bool wide = P.mixed_cls == 0 || P.mixed_cls == 3;
   if (use_fused2(P) && !(wide && P.pow2_part)) return run_prog(P, inverse ? P.prog_crtinv_fused : P.prog_crt_fused, s, y, B);
-  if (P.pow2_part && !getenv("LOLHIP_NO_POW2_PART")) {
+  if (P.pow2_part && !sw(SW_NO_POW2_PART)) {
     const int64_t blocks = B * (P.n >> P.pow2.L);       // contiguous 2^(e-1)-coefficient blocks
     if (!inverse) {
       int rc = run_pow2(P, 0, s, y, nullptr, nullptr, blocks);
@@ -171,6 +193,19 @@ extern "C" {
 int lolhip_device_count(void) { return device_count(); }
 const char* lolhip_version(void) { return "lolhip 0.1 (gfx950)"; }
 int lolhip_last_status(void) { return g_last_status; }
+int lolhip_copy_slab(void* stream, void* dst, const void* src, int64_t bytes, int variant) {
+  if (bytes < 0 || (bytes && (!dst || !src))) return LOLHIP_ERR_INVALID;
+  if (device_count() == 0) return LOLHIP_ERR_NO_DEVICE;
+  const hipError_t e = launch_copy16((hipStream_t)stream, dst, src, (size_t)bytes, variant);
+  return e == hipSuccess ? LOLHIP_OK : e == hipErrorInvalidValue ? LOLHIP_ERR_INVALID : LOLHIP_ERR_HIP;
+}
+int lolhip_debug_set(const char* name, int value) {
+  if (!name) return LOLHIP_ERR_INVALID;
+  switches_init();
+  for (int i = 0; i < SW_COUNT; ++i)
+    if (!strcmp(name, kSwitchNames[i])) { g_switch[i].store(value ? 1 : 0, std::memory_order_relaxed); return LOLHIP_OK; }
+  return LOLHIP_ERR_INVALID;
+}
 
 int lolhip_plan_create(const lolhip_pp* pps, int npps, const int64_t* qs, int T, int host_only, lolhip_plan** out) {
   return make_plan(pps, npps, qs, T, nullptr, nullptr, host_only, out);
@@ -242,9 +277,9 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   const Plan& P = p->P;
   hipStream_t s = (hipStream_t)stream;
   if (P.is_pow2) return run_pow2(P, 2, s, c, a, b, B);
-  static const bool unfused = getenv("LOLHIP_POLYMUL_UNFUSED") != nullptr;          // A/B switch
+  const bool unfused = sw(SW_POLYMUL_UNFUSED);                                      // A/B switch
   const bool fused2 = use_fused2(P);
-  const bool split2 = !fused2 && P.pow2_part && !getenv("LOLHIP_NO_POW2_PART");   // the 2-power factor has its own kernels
+  const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);   // the 2-power factor has its own kernels
   if (!unfused && !split2 && (fused2 || (use_mixed(P, P.prog_crt) && use_mixed(P, P.prog_crtinv)))) {
     // one launch: a-hat in registers, b through the same LDS buffer, 3 slab passes (mixed.hip)
     const StageProgram& pf = fused2 ? P.prog_crt_fused : P.prog_crt;
@@ -264,7 +299,7 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   if (!tmpbuf.alloc(bytes)) return LOLHIP_ERR_HIP;
   int64_t* tmp = (int64_t*)tmpbuf.p;
   rc = LOLHIP_OK;
-  if (!P.pow2_part || getenv("LOLHIP_NO_POW2_PART")) {
+  if (!P.pow2_part || sw(SW_NO_POW2_PART)) {
     // stage program alone: transform b into the temp first (c may alias b), then a into c
     rc = run_prog(P, P.prog_crt, s, tmp, B, b);
     if (!rc) rc = run_prog(P, P.prog_crt, s, c, B, c != a ? a : nullptr);
@@ -444,7 +479,7 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
   if (B == 0) return LOLHIP_OK;
   // one fused pass when the plan is in the 32-bit class of the m = 2^k path (every q_t < 2^30)
   if (P.is_pow2 && (P.pow2.arith32 == 2 || P.pow2.arith32 == 4) && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
-      (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !getenv("LOLHIP_KEYSWITCH_UNFUSED")) {
+      (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !sw(SW_KEYSWITCH_UNFUSED)) {
     KeySwitchLaunch l;
     l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B;
     l.T = P.T; l.L = P.pow2.L; l.tw_fwd32 = P.pow2.d_tw_fwd32; l.mod = P.d_mod; l.dp = d; l.arith = P.pow2.arith32;

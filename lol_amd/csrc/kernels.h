@@ -85,6 +85,8 @@ hipError_t launch_mixed(const MixedLaunch& a);
 hipError_t launch_cplx(hipStream_t s, double* y, i64 B, i64 n, const Stage* stages, int nstages, const double* cconsts);
 hipError_t launch_gauss(hipStream_t s, double* y, i64 B, i64 n, const Stage* stages, int nstages, const double* rconsts);
 
+// 16-byte-per-lane copy of a slab: the measured ceiling of a read-once/write-once kernel (bench.py's yardstick)
+hipError_t launch_copy16(hipStream_t s, void* dst, const void* src, size_t bytes, int variant);
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod);
 // replicating: every output has a source (embedCRT) — worth staging the source polynomial in LDS
 hipError_t launch_gather(hipStream_t s, i64* out, const i64* in, const int32_t* idx, i64 B, i64 n_out, i64 n_in,

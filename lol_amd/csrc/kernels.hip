@@ -19,18 +19,24 @@
 namespace lolhip {
 
 // the arithmetic classes of the m = 2^k path live in pow2_ar{0,1,2,3}.hip
-extern template hipError_t launch_pow2_ar<0>(const Pow2Launch&, int);
-extern template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
-extern template hipError_t launch_pow2_ar<2>(const Pow2Launch&, int);
-extern template hipError_t launch_pow2_ar<3>(const Pow2Launch&, int);
-extern template hipError_t launch_pow2_ar<4>(const Pow2Launch&, int);
+#define LOLHIP_POW2_EXTERN(AR) \
+  extern template hipError_t launch_pow2_ar<AR, false>(const Pow2Launch&, int); \
+  extern template hipError_t launch_pow2_ar<AR, true>(const Pow2Launch&, int);
+LOLHIP_POW2_EXTERN(0) LOLHIP_POW2_EXTERN(1) LOLHIP_POW2_EXTERN(2) LOLHIP_POW2_EXTERN(3) LOLHIP_POW2_EXTERN(4)
+#undef LOLHIP_POW2_EXTERN
+template <int AR> static hipError_t launch_pow2_class(const Pow2Launch& a, int mode) {
+  // one modulus and 16-byte-aligned slabs: the variant that moves 16 bytes per lane
+  const uintptr_t al = (uintptr_t)a.y | (mode == 2 ? ((uintptr_t)a.a | (uintptr_t)a.b) : 0);
+  const bool t1 = a.T == 1 && (al & 15) == 0 && !pow2_no_t1();
+  return t1 ? launch_pow2_ar<AR, true>(a, mode) : launch_pow2_ar<AR, false>(a, mode);
+}
 hipError_t launch_pow2(const Pow2Launch& a, int mode) {
   switch (a.arith) {
-    case 0: return launch_pow2_ar<0>(a, mode);
-    case 1: return launch_pow2_ar<1>(a, mode);
-    case 2: return launch_pow2_ar<2>(a, mode);
-    case 3: return launch_pow2_ar<3>(a, mode);
-    case 4: return launch_pow2_ar<4>(a, mode);
+    case 0: return launch_pow2_class<0>(a, mode);
+    case 1: return launch_pow2_class<1>(a, mode);
+    case 2: return launch_pow2_class<2>(a, mode);
+    case 3: return launch_pow2_class<3>(a, mode);
+    case 4: return launch_pow2_class<4>(a, mode);
     default: return hipErrorInvalidValue;
   }
 }
@@ -474,15 +480,87 @@ k_pointwise_mul(i64* __restrict__ a, const i64* __restrict__ b, i64 total, i64 b
   }
 }
 
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+// the same, two consecutive elements (16 bytes) per lane and access: even total and period, 16-byte-aligned
+// slabs (whatever T: the two elements of a pair take their own modulus)
+constexpr int PW2_K = 4;                    // pairs per thread
+__global__ void __launch_bounds__(256)
+k_pointwise_mul2(i64* __restrict__ a, const i64* __restrict__ b, i64 total, i64 bperiod, int T,
+                 const ModCtx* __restrict__ mod) {
+  const i64 s0 = (i64)blockIdx.x * (512 * PW2_K);         // first element of the tile (wave-uniform)
+  const bool flat = (bperiod >= total);
+  const u32 t_s = (u32)((u64)s0 % (u32)T);
+  const u32 r_s = flat ? 0u : (u32)((u64)s0 % (u64)bperiod);
+  const u32 per = (u32)bperiod;
+  u64x2 x[PW2_K], z[PW2_K];
+#pragma unroll
+  for (int k = 0; k < PW2_K; ++k) {
+    const u32 l = ((u32)k * 256u + threadIdx.x) * 2u;
+    const i64 i = s0 + l;
+    if (i < total) {
+      x[k] = *reinterpret_cast<const u64x2*>(a + i);
+      z[k] = *reinterpret_cast<const u64x2*>(b + (flat ? i : (i64)((r_s + l) % per)));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PW2_K; ++k) {
+    const u32 l = ((u32)k * 256u + threadIdx.x) * 2u;
+    const i64 i = s0 + l;
+    if (i < total) {
+      const ModCtx m0 = mod[T == 1 ? 0u : (t_s + l) % (u32)T];
+      const ModCtx m1 = mod[T == 1 ? 0u : (t_s + l + 1u) % (u32)T];
+      u64x2 r;
+      r.x = mulmod(canon_in((i64)x[k].x, m0.q), canon_in((i64)z[k].x, m0.q), m0);
+      r.y = mulmod(canon_in((i64)x[k].y, m1.q), canon_in((i64)z[k].y, m1.q), m1);
+      *reinterpret_cast<u64x2*>(a + i) = r;
+    }
+  }
+}
+
 hipError_t launch_pointwise_mul(hipStream_t s, i64* a, const i64* b, i64 total, i64 bperiod, int T, const ModCtx* mod) {
   if (total == 0) return hipSuccess;
+  if ((((uintptr_t)a | (uintptr_t)b) & 15) == 0 && total % 2 == 0 && (bperiod >= total || bperiod % 2 == 0)) {
+    const i64 blocks = (total + 512 * PW2_K - 1) / (512 * PW2_K);
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pointwise_mul2, dim3((unsigned)blocks), dim3(256), 0, s, a, b, total, bperiod, T, mod);
+    return hipGetLastError();
+  }
   const i64 blocks = (total + 256 * PW_K - 1) / (256 * PW_K);
   if (blocks > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_pointwise_mul, dim3((unsigned)blocks), dim3(256), 0, s, a, b, total, bperiod, T, mod);
   return hipGetLastError();
 }
 
-typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+// ---- the yardstick: a read-once / write-once copy of a slab, 16 bytes per lane ----------------
+// What a streaming kernel with no arithmetic reaches on this part; bench.py reports every HBM-bound
+// leg beside it (MI355X_MICROARCH.md measures 6.29 TB/s of the 8 TB/s datasheet peak this way).
+// variant 0: one 16 KiB tile per 256-thread workgroup, all loads issued before the stores;
+// variant 1: 2048 persistent workgroups walking the slab with the same tile.
+template <bool PERSIST>
+__global__ void __launch_bounds__(256)
+k_copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, u64 nvec) {
+  constexpr int K = 4;
+  const u64 ntiles = (nvec + 256 * K - 1) / (256 * K);
+  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const u64 base = tile * (256 * K) + threadIdx.x;
+    u32x4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (base + (u64)k * 256 < nvec) v[k] = src[base + (u64)k * 256];
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (base + (u64)k * 256 < nvec) dst[base + (u64)k * 256] = v[k];
+    if constexpr (!PERSIST) break;
+  }
+}
+hipError_t launch_copy16(hipStream_t s, void* dst, const void* src, size_t bytes, int variant) {
+  if (bytes == 0) return hipSuccess;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) || bytes % 16) return hipErrorInvalidValue;
+  const u64 nvec = bytes / 16, ntiles = (nvec + 1023) / 1024;
+  if (variant == 1) hipLaunchKernelGGL((k_copy16<true>), dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), 0, s, (u32x4*)dst, (const u32x4*)src, nvec);
+  else if (ntiles > 0x7fffffff) return hipErrorInvalidValue;
+  else hipLaunchKernelGGL((k_copy16<false>), dim3((unsigned)ntiles), dim3(256), 0, s, (u32x4*)dst, (const u32x4*)src, nvec);
+  return hipGetLastError();
+}
+
 // TW consecutive components of one coefficient (16-byte accesses when T is even and the slabs are aligned)
 template <int TW> struct Chunk { u64 v[TW]; };
 template <int TW> __device__ __forceinline__ Chunk<TW> load_chunk(const i64* p) {

@@ -1,5 +1,5 @@
 // lol_amd/csrc/pow2_ar0.hip — the m = 2^k kernels of arithmetic class AR = 0 (see pow2_impl.h)
 #include "pow2_impl.h"
 namespace lolhip {
-template hipError_t launch_pow2_ar<0>(const Pow2Launch&, int);
+template hipError_t launch_pow2_ar<0, false>(const Pow2Launch&, int);
 }  // namespace lolhip

@@ -1,7 +1,7 @@
 // lol_amd/csrc/pow2_ar1.hip — the m = 2^k kernels of arithmetic class AR = 1 (see pow2_impl.h)
 #include "pow2_impl.h"
 namespace lolhip {
-template hipError_t launch_pow2_ar<1>(const Pow2Launch&, int);
+template hipError_t launch_pow2_ar<1, false>(const Pow2Launch&, int);
 }  // namespace lolhip
 #if defined(LOLHIP_STAMPS) && LOLHIP_STAMPS == 1      // diagnostic build only (make ... CXXFLAGS+=-DLOLHIP_STAMPS=1): phase stamps of THIS class
 extern "C" __attribute__((visibility("default"))) int lolhip_debug_set_stamps(unsigned long long* dev) {

@@ -365,6 +365,50 @@ __device__ __forceinline__ void store_u64(rsrc_t r, u32 voff, u32 soff, u64 val)
   __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 
+// 16 bytes per lane: coefficients x, x+1 of a single-modulus slab
+__device__ __forceinline__ void load_u64x2(rsrc_t r, u32 voff, u32 soff, u64& x0, u64& x1) {
+#ifdef LOLHIP_ABL_NO_IO
+  x0 = (u64)voff * 0x9E3779B97F4A7C15ull + soff; x1 = x0 ^ soff; return;
+#endif
+  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  x0 = ((u64)x.y << 32) | x.x;
+  x1 = ((u64)x.w << 32) | x.z;
+}
+__device__ __forceinline__ void store_u64x2(rsrc_t r, u32 voff, u32 soff, u64 x0, u64 x1) {
+  u32x4 x;
+  x.x = (u32)x0; x.y = (u32)(x0 >> 32); x.z = (u32)x1; x.w = (u32)(x1 >> 32);
+#ifdef LOLHIP_ABL_NO_IO
+  if (x0 != 0x1234567ull) return;
+#endif
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+}
+// whole-polynomial register I/O in layout A; element stride `ebytes` (= 8 T).  Layouts whose
+// register bit 0 is position bit 0 (Sched<L, true>) move pairs with 16-byte accesses.
+template <Lay A, bool W16, typename F>
+__device__ __forceinline__ void load_poly(rsrc_t r, u32 off, u32 ebytes, F&& put) {
+  if constexpr (W16 && A.reg[0] == 0) {
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+      u64 x0, x1;
+      load_u64x2(r, off, (u32)lay_tab<A>.xr[e] * 8u, x0, x1);
+      put(e, x0); put(e + 1, x1);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) put(e, load_u64(r, off, (u32)lay_tab<A>.xr[e] * ebytes));
+  }
+}
+template <Lay A, bool W16, typename F>
+__device__ __forceinline__ void store_poly(rsrc_t r, u32 off, u32 ebytes, F&& get) {
+  if constexpr (W16 && A.reg[0] == 0) {
+#pragma unroll
+    for (int e = 0; e < E; e += 2) store_u64x2(r, off, (u32)lay_tab<A>.xr[e] * 8u, get(e), get(e + 1));
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) store_u64(r, off, (u32)lay_tab<A>.xr[e] * ebytes, get(e));
+  }
+}
+
 // Where a level's twiddles come from:
 //  * index bits all on registers (the thread part of x mod 2^beta is empty): wave-uniform,
 //    read with SCALAR loads — no texture-path traffic at all;
@@ -577,7 +621,12 @@ constexpr Lay lay_make(int L, int r0, int r1, int r2, int r3, const int* thr_bit
 // and the remaining L-10 levels after ONE cross-wave transpose into
 //   G:  registers = bits L-4..L-1                   -> levels 11..L
 // G is also the coalesced global-memory layout (consecutive lanes = consecutive coefficients).
-template <int L> struct Sched {
+// W16 (single-modulus launches, 16-byte-aligned slabs): the two layouts that touch global memory
+// keep position bit 0 on REGISTER bit 0, so a lane moves coefficients x, x+1 with one
+// buffer_load/store_dwordx4 (16 B per lane, 1 KiB per wave-instruction: half the vector-memory
+// instructions of the 8 B form).  G has a spare register bit for that up to L = 13 (level 10 is
+// reached by a lane swap, so G's lowest register bit carries no level).
+template <int L, bool W16 = false> struct Sched {
   static constexpr int NTB = L - R;
   static constexpr int LW = L < 10 ? L : 10;
   static constexpr bool HAS_G = L > 10;
@@ -594,10 +643,20 @@ template <int L> struct Sched {
   static constexpr Lay w1a() { return lay_swap(w1(), 4, 3); }    // lane bit 4 <-> register bit 3: bit 8
   static constexpr Lay w1b() { return lay_swap(w1a(), 5, 2); }   // lane bit 5 <-> register bit 2: bit 9
   static constexpr Lay wave_end() { return NSWAP == 2 ? w1b() : NSWAP == 1 ? w1a() : HAS_W1 ? w1() : w0(); }
-  static constexpr Lay g() { return lay_std(L, L - R); }
+  static constexpr bool G16 = W16 && L > 10 && L <= 13;
+  static constexpr Lay g() {
+    if (!G16) return lay_std(L, L - R);
+    int thr[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};       // bits 1..L-4 (only the first L-4 are used)
+    return lay_make(L, 0, L - 3, L - 2, L - 1, thr);
+  }
   static constexpr int G_K0 = R - (L - 10);                      // first register bit with work in G
   // coalesced load/store layout for powerful-basis data that keeps a wave inside its block
   static constexpr Lay io() {
+    if (W16) {
+      if (L < 10) { int thr[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12}; return lay_make(L, 0, L - 3, L - 2, L - 1, thr); }
+      int thr[12] = {1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15};
+      return lay_make(L, 0, 7, 8, 9, thr);
+    }
     if (L < 10) return lay_std(L, L - R);
     int thr[12] = {0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15};
     return lay_make(L, 6, 7, 8, 9, thr);
@@ -658,10 +717,10 @@ __device__ __forceinline__ int fresh(int x) {
   return x;
 }
 
-template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false>
+template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false, bool W16 = false>
 __device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
   using LevelTw = LevelTwT<VT<AR>>;
-  using S = Sched<L>;
+  using S = Sched<L, W16>;
   {   // W0: levels 1..4
     constexpr Lay A = S::w0();
     const int tau = fresh(tau_in);
@@ -728,10 +787,10 @@ __device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const
 }
 
 // inverse transform; data arrives in Sched<L>::final_layout(), leaves in layout NEXT
-template <int AR, int L, Lay NEXT>
+template <int AR, int L, Lay NEXT, bool W16 = false>
 __device__ __forceinline__ void inv_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
   using LevelTw = LevelTwT<VT<AR>>;
-  using S = Sched<L>;
+  using S = Sched<L, W16>;
   if constexpr (S::HAS_G) {
     constexpr Lay A = S::g();
     const int tau = fresh(tau_in);
@@ -776,15 +835,15 @@ __device__ __forceinline__ void inv_transform(VT<AR> (&v)[E], VT<AR>* lds, const
 constexpr int pow2_threads(int L) { return (1 << (L - R)) >= 256 ? (1 << (L - R)) : 256; }
 
 // MODE 0: crt in place, 1: crtInv in place, 2: c = crtInv(crt(a) * crt(b))
-// TU ("T uniform"): the launch has a single modulus, so t = 0 for every lane even when a wave
-// holds several short polynomials — the per-modulus constants stay in SGPRs (instantiated for
-// n <= 512 only; longer polynomials own whole waves and are uniform anyway)
-template <int L, int MODE, int AR, bool TU = false>
+// T1: the launch has a single modulus (T = 1) and 16-byte-aligned slabs: t = 0 for every lane even
+// when a wave holds several short polynomials — the per-modulus constants stay in SGPRs — and
+// global memory moves 16 bytes per lane (Sched<L, true>)
+template <int L, int MODE, int AR, bool T1 = false>
 __global__ void __launch_bounds__(pow2_threads(L), AR >= 2 ? 8 : 4)
 k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
        const VT<AR>* __restrict__ tw_fwd, const VT<AR>* __restrict__ tw_inv, const VT<AR>* __restrict__ scale,
        const ModCtx* __restrict__ mod, int xcd_map) {
-  using S = Sched<L>;
+  using S = Sched<L, T1>;
   using V = VT<AR>;
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);                  // threads per polynomial
@@ -795,6 +854,7 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   V* lds = reinterpret_cast<V*>(smem) + (threadIdx.x / NT) * LDSW;
   V* lds_tw = lds + n + n / 16;
   const int tau = threadIdx.x % NT;
+  if constexpr (T1) T = 1;
 
   // work item -> (b, t); with xcd_map the T components of one polynomial land on
   // workgroups that share an XCD (equal blockIdx % 8) so its cache lines are
@@ -805,14 +865,14 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
   i64 b, b0; int t;
   if (xcd_map) { i64 g = item / (8 * (i64)T); int r = (int)(item % (8 * T)); b = g * 8 + (r & 7); t = r >> 3; b0 = b; }
   else { b = item / T; t = (int)(item % T); b0 = item0 / T; }
-  if constexpr (TU) { b = item; t = 0; b0 = item0; }
+  if constexpr (T1) { b = item; t = 0; b0 = item0; }
 
   if constexpr (NT >= 64) {           // a wave never straddles two polynomials: make that provable to hipcc
     t = __builtin_amdgcn_readfirstlane(t);
     b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b));
   }
   b0 = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)b0));
-  const QKT<AR> qk(mod[t], std::bool_constant<(NT >= 64 || TU)>{});
+  const QKT<AR> qk(mod[t], std::bool_constant<(NT >= 64 || T1)>{});
   // Buffer descriptors (wave-uniform): data windows start at the workgroup's first polynomial
   // and end at the end of the batch, so tail lanes of a packed launch read zeros and their
   // stores are dropped by the hardware range check.
@@ -858,10 +918,9 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
 #endif
   if constexpr (MODE == 0 || MODE == 2) {
     const rsrc_t src = (MODE == 2) ? ra : ry;
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64_fwd<AR>((i64)load_u64(src, off_io, (u32)lay_tab<LIO>.xr[e] * uT8), qk);
+    load_poly<LIO, T1>(src, off_io, uT8, [&](int e, u64 x) { v[e] = from_i64_fwd<AR>((i64)x, qk); });
     LH_STAMP(1);
-    fwd_transform<AR, L, LIO>(v, lds, tw, tau, qk);
+    fwd_transform<AR, L, LIO, 0, false, T1>(v, lds, tw, tau, qk);
     if constexpr (MODE == 0) LH_STAMP(20);
   }
   if constexpr (MODE == 2) {
@@ -877,15 +936,14 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
       // (issuing these with a's loads and holding the 32 raw registers across a's transform
       // was measured: no gain at q ~ 2^30, 7% slower in class 4 — 6 instead of 8 waves/SIMD)
       u64 raw[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) raw[e] = load_u64(rb, off_io, (u32)lay_tab<LIO>.xr[e] * uT8);
+      load_poly<LIO, T1>(rb, off_io, uT8, [&](int e, u64 x) { raw[e] = x; });
       // keep the 16 loads back to back: at this register pressure the scheduler otherwise
       // sinks each load to its use and the wave pays 16 serial HBM round trips
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = from_i64_fwd<AR>((i64)raw[e], qk);
       LH_STAMP(11);
-      fwd_transform<AR, L, LIO, 10, true>(v, lds, tw, tau, qk);
+      fwd_transform<AR, L, LIO, 10, true, T1>(v, lds, tw, tau, qk);
     }
     LH_STAMP(19);
     const ModCtx mc = mod[t];     // re-read here: keeping it live across the transforms costs registers
@@ -900,19 +958,16 @@ k_pow2(i64* y, const i64* a_in, const i64* b_in, i64 B, int T,
     tw_fill_lds<NT>(lds_tw, tw.inv, tw.comp, n, tau);
   }
   if constexpr (MODE == 1) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = from_i64_inv<AR>((i64)load_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8), qk);
+    load_poly<LFIN, T1>(ry, off_fin, uT8, [&](int e, u64 x) { v[e] = from_i64_inv<AR>((i64)x, qk); });
   }
   if constexpr (MODE == 0) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_fin, (u32)lay_tab<LFIN>.xr[e] * uT8, (u64)canon_fwd<AR>(v[e], qk));
+    store_poly<LFIN, T1>(ry, off_fin, uT8, [&](int e) { return (u64)canon_fwd<AR>(v[e], qk); });
     LH_STAMP(21);
   } else {
     LH_STAMP(23);
-    inv_transform<AR, L, LIO>(v, lds, tw, tau, qk);
+    inv_transform<AR, L, LIO, T1>(v, lds, tw, tau, qk);
     LH_STAMP(24);
-#pragma unroll
-    for (int e = 0; e < E; ++e) store_u64(ry, off_io, (u32)lay_tab<LIO>.xr[e] * uT8, (u64)canon_inv<AR>(v[e], qk));
+    store_poly<LIO, T1>(ry, off_io, uT8, [&](int e) { return (u64)canon_inv<AR>(v[e], qk); });
     LH_STAMP(25);
   }
 }
@@ -941,7 +996,7 @@ static hipError_t kernel_dev_setup(KernelDev (&tab)[MAX_DEV], Setup&& setup) {
   return hipSuccess;
 }
 
-template <int L, int MODE, int AR>
+template <int L, int MODE, int AR, bool T1>
 static hipError_t launch_pow2_L(const Pow2Launch& a) {
   constexpr int n = 1 << L;
   constexpr int NT = 1 << (L - R);
@@ -955,53 +1010,42 @@ static hipError_t launch_pow2_L(const Pow2Launch& a) {
   if (lds_bytes > 64 * 1024) {
     static KernelDev tab[MAX_DEV];
     hipError_t e = kernel_dev_setup(tab, [&]() -> hipError_t {
-      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (r == hipSuccess && NT < 64 && AR < 2)
-        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      return r;
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pow2<L, MODE, AR, T1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     if (e != hipSuccess) return e;
   }
-  if constexpr (NT < 64 && AR < 2) {
-    if (a.T == 1) {
-      hipLaunchKernelGGL((k_pow2<L, MODE, AR, true>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
-                         a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
-                         static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
-      return hipGetLastError();
-    }
-  }
-  hipLaunchKernelGGL((k_pow2<L, MODE, AR>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
+  hipLaunchKernelGGL((k_pow2<L, MODE, AR, T1>), dim3((unsigned)grid), dim3(NT * PPW), lds_bytes, a.stream,
                      a.y, a.a, a.b, a.B, a.T, static_cast<const VT<AR>*>(a.tw_fwd), static_cast<const VT<AR>*>(a.tw_inv),
                      static_cast<const VT<AR>*>(a.scale), a.mod, xcd_map);
   return hipGetLastError();
 }
 
-template <int MODE, int AR>
+template <int MODE, int AR, bool T1>
 static hipError_t launch_pow2_mode(const Pow2Launch& a) {
   switch (a.L) {
-    case 4: return launch_pow2_L<4, MODE, AR>(a);
-    case 5: return launch_pow2_L<5, MODE, AR>(a);
-    case 6: return launch_pow2_L<6, MODE, AR>(a);
-    case 7: return launch_pow2_L<7, MODE, AR>(a);
-    case 8: return launch_pow2_L<8, MODE, AR>(a);
-    case 9: return launch_pow2_L<9, MODE, AR>(a);
-    case 10: return launch_pow2_L<10, MODE, AR>(a);
-    case 11: return launch_pow2_L<11, MODE, AR>(a);
-    case 12: return launch_pow2_L<12, MODE, AR>(a);
-    case 13: return launch_pow2_L<13, MODE, AR>(a);
-    case 14: return launch_pow2_L<14, MODE, AR>(a);
+    case 4: return launch_pow2_L<4, MODE, AR, T1>(a);
+    case 5: return launch_pow2_L<5, MODE, AR, T1>(a);
+    case 6: return launch_pow2_L<6, MODE, AR, T1>(a);
+    case 7: return launch_pow2_L<7, MODE, AR, T1>(a);
+    case 8: return launch_pow2_L<8, MODE, AR, T1>(a);
+    case 9: return launch_pow2_L<9, MODE, AR, T1>(a);
+    case 10: return launch_pow2_L<10, MODE, AR, T1>(a);
+    case 11: return launch_pow2_L<11, MODE, AR, T1>(a);
+    case 12: return launch_pow2_L<12, MODE, AR, T1>(a);
+    case 13: return launch_pow2_L<13, MODE, AR, T1>(a);
+    case 14: return launch_pow2_L<14, MODE, AR, T1>(a);
     default: return hipErrorInvalidValue;
   }
 }
 
-template <int AR>
+// T1: single-modulus launches whose slabs are 16-byte aligned (checked by launch_pow2, kernels.hip)
+template <int AR, bool T1>
 hipError_t launch_pow2_ar(const Pow2Launch& a, int mode) {
   switch (mode) {
-    case 0: return launch_pow2_mode<0, AR>(a);
-    case 1: return launch_pow2_mode<1, AR>(a);
-    case 2: return launch_pow2_mode<2, AR>(a);
+    case 0: return launch_pow2_mode<0, AR, T1>(a);
+    case 1: return launch_pow2_mode<1, AR, T1>(a);
+    case 2: return launch_pow2_mode<2, AR, T1>(a);
     default: return hipErrorInvalidValue;
   }
 }

@@ -134,6 +134,8 @@ def lib():
     L.lolhip_tunnelhint_read.argtypes = [u8p, i64, u32p, u32p, u32p, C.POINTER(C.c_uint64), _i64p, _i64p, _i64p, _i64p, ci]
     for nm in ("r_read", "secretkey_read", "kqproduct_read", "linearrq_read", "kshint_write", "tunnelhint_read"):
         getattr(L, f"lolhip_{nm}").restype = i64
+    L.lolhip_debug_set.argtypes = [C.c_char_p, ci]
+    L.lolhip_copy_slab.argtypes = [vp, vp, vp, i64, ci]
     L.lolhip_device_count.restype = ci
     L.lolhip_version.restype = C.c_char_p
     L.lolhip_last_status.restype = ci
@@ -149,6 +151,11 @@ def _check(rc, what=""):
 
 def device_count() -> int:
     return lib().lolhip_device_count()
+
+
+def debug_set(name: str, value: bool) -> None:
+    """Force (value true) or release a launch path of the library: lolhip_debug_set (tests, A/B runs)."""
+    _check(lib().lolhip_debug_set(name.encode(), 1 if value else 0), f"lolhip_debug_set({name})")
 
 
 def good_q(m: int, lower: int) -> int:

@@ -54,3 +54,16 @@ def gpu(lolhip):
     if lolhip.device_count() == 0:
         pytest.fail("-m gpu tests need a GPU: liblolhip has no CPU fallback")
     return lolhip
+
+
+SWITCHES = ("GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED", "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE")
+
+
+@pytest.fixture(autouse=True)
+def _release_forced_paths():
+    """A test that forces a launch path (lol_amd.debug_set) and fails must not leave it forced."""
+    yield
+    import lol_amd.tensor as t
+    if t._lib is not None:
+        for nm in SWITCHES:
+            t._lib.lolhip_debug_set(nm.encode(), 0)

@@ -14,6 +14,7 @@ hipError_t launch_mixed(const MixedLaunch&) { return hipErrorNoDevice; }
 hipError_t launch_cplx(hipStream_t, double*, i64, i64, const Stage*, int, const double*) { return hipErrorNoDevice; }
 hipError_t launch_gauss(hipStream_t, double*, i64, i64, const Stage*, int, const double*) { return hipErrorNoDevice; }
 hipError_t launch_pointwise_mul(hipStream_t, i64*, const i64*, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
+hipError_t launch_copy16(hipStream_t, void*, const void*, size_t, int) { return hipErrorNoDevice; }
 hipError_t launch_gather(hipStream_t, i64*, const i64*, const int32_t*, i64, i64, i64, int, const ModCtx*, bool) { return hipErrorNoDevice; }
 hipError_t launch_twace_crt(hipStream_t, i64*, const i64*, const int32_t*, const i64*, i64, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
 hipError_t launch_ctmul(hipStream_t, const i64*, const i64*, const i64*, const i64*, i64*, i64*, i64*, const i64*, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }

@@ -196,6 +196,58 @@ def test_pow2_all_sizes(gpu, cpuref, L, T, lower):
         assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y))       # squaring path (a is b)
 
 
+@pytest.mark.parametrize("L", range(4, 15))
+def test_pow2_16_byte_and_8_byte_global_access(gpu, cpuref, L):
+    """Single-modulus launches move 16 bytes per lane when the slabs are 16-byte aligned (k_pow2<..., T1>);
+    8-byte-aligned slabs and the forced switch take the 8-byte kernels.  All agree with the oracle in every
+    arithmetic class, incl. reference-style negative representatives and a ragged last workgroup."""
+    torch = pytest.importorskip("torch")
+    m = 2 ** (L + 1)
+    for lower in (2 ** 20, 2 ** 29, 2 ** 30, 2 ** 58, 2 ** 61):
+        q = lm.first_good_q(m, lower)
+        P, R = gpu.Plan([(2, L + 1)], [q]), Params([(2, L + 1)], [q])
+        rng = np.random.default_rng(L + lower % 97)
+        B = 7
+        y, z = R.random(rng, B), R.random(rng, B)
+        y[0] = np.where(y[0] > 0, y[0] - q, 0)                        # (-q, 0] representatives
+        want = cpuref.crt(R, y), cpuref.crtinv(R, y), cpuref.polymul(R, y, z), cpuref.mul(R, y, z)
+        for forced in (False, True):
+            gpu.debug_set("NO_T1", forced)
+            assert np.array_equal(P.crt(y), want[0]), (L, q, forced)
+            assert np.array_equal(P.crtInv(y), want[1]), (L, q, forced)
+            assert np.array_equal(P.polymul(y, z), want[2]), (L, q, forced)
+        gpu.debug_set("NO_T1", False)
+        # slabs that are only 8-byte aligned: one int64 into a 16-byte-aligned allocation
+        n = R.n
+        pad_a = torch.zeros(B * n + 1, dtype=torch.int64, device="cuda")
+        pad_b = torch.zeros(B * n + 1, dtype=torch.int64, device="cuda")
+        pad_c = torch.zeros(B * n + 1, dtype=torch.int64, device="cuda")
+        da, db, dc = (t[1:].view(B, n, 1) for t in (pad_a, pad_b, pad_c))
+        assert da.data_ptr() % 16 == 8
+        da.copy_(torch.from_numpy(y)); db.copy_(torch.from_numpy(z))
+        P.polymul(da, db, out=dc)
+        assert np.array_equal(dc.cpu().numpy(), want[2]), (L, q, "misaligned polymul")
+        x = da.clone()                                                 # clone: 16-byte aligned again
+        P.mul(x, db)                                                   # one aligned, one not
+        assert np.array_equal(x.cpu().numpy(), want[3]), (L, q, "mul mixed alignment")
+        P.crt(da); assert np.array_equal(da.cpu().numpy(), want[0]), (L, q, "misaligned crt")
+        da.copy_(torch.from_numpy(y)); P.crtInv(da)
+        assert np.array_equal(da.cpu().numpy(), want[1]), (L, q, "misaligned crtInv")
+        assert int(pad_a[0]) == 0 and int(pad_c[0]) == 0              # nothing written in front of the slab
+
+
+def test_copy_slab_yardstick(gpu):
+    torch = pytest.importorskip("torch")
+    src = torch.randint(0, 2 ** 62, (1 << 20,), dtype=torch.int64, device="cuda")
+    for variant in (0, 1):
+        for cnt in (1 << 20, 1026, 2):
+            dst = torch.zeros_like(src)
+            assert gpu.lib().lolhip_copy_slab(None, dst.data_ptr(), src.data_ptr(), cnt * 8, variant) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(dst[:cnt], src[:cnt]) and int(dst[cnt:].abs().sum()) == 0
+    assert gpu.lib().lolhip_copy_slab(None, src.data_ptr() + 8, src.data_ptr(), 16, 0) != 0    # misaligned: refused
+
+
 @pytest.mark.parametrize("m", [3, 5, 9, 15, 21, 25, 27, 33, 36, 45, 49, 63, 89, 105, 121, 280, 432, 1155, 1728, 5184, 14400, 15015])
 def test_generic_indices(gpu, cpuref, m):
     pps = lm.factor_pps(m)
@@ -234,17 +286,15 @@ def test_two_power_factor_routes(gpu, cpuref, monkeypatch, m):
         y, z = R.random(rng, 5), R.random(rng, 5)
         want = cpuref.crt(R, y), cpuref.crtinv(R, y), cpuref.polymul(R, y, z)
         for route in ("fused", "split", "stages"):
-            if route != "fused":
-                monkeypatch.setenv("LOLHIP_NO_FUSED2", "1")
-            if route == "stages":
-                monkeypatch.setenv("LOLHIP_NO_POW2_PART", "1")
+            gpu.debug_set("NO_FUSED2", route != "fused")
+            gpu.debug_set("NO_POW2_PART", route == "stages")
             P = gpu.Plan(pps, qs)
             assert np.array_equal(P.crt(y), want[0]), (m, qs, route)
             assert np.array_equal(P.crtInv(y), want[1]), (m, qs, route)
             assert np.array_equal(P.polymul(y, z), want[2]), (m, qs, route)
             assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y)), (m, qs, route)
-            monkeypatch.delenv("LOLHIP_NO_POW2_PART", raising=False)
-            monkeypatch.delenv("LOLHIP_NO_FUSED2", raising=False)
+            gpu.debug_set("NO_POW2_PART", False)
+            gpu.debug_set("NO_FUSED2", False)
 
 
 @pytest.mark.parametrize("m,q", BENCH1)

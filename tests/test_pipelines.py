@@ -290,16 +290,16 @@ def test_gpu_keyswitch_fused_all_sizes(gpu, cpuref, monkeypatch, L):
         assert np.array_equal(got, want), (L, base)
         wadd = ((want.astype(object) + add) % np.array(qs, dtype=object)).astype(np.int64)
         assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (L, base)
-        monkeypatch.setenv("LOLHIP_KEYSWITCH_UNFUSED", "1")
+        gpu.debug_set("KEYSWITCH_UNFUSED", True)
         assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (L, base, "unfused")
-        monkeypatch.delenv("LOLHIP_KEYSWITCH_UNFUSED")
+        gpu.debug_set("KEYSWITCH_UNFUSED", False)
         # every operand may be a reference-style representative in (-q, 0]: the hint as well
         qv = np.array(qs)
         neg = lambda x: np.where(x > 0, x - qv, 0)
         assert np.array_equal(P.keySwitch(neg(c2), base, neg(hint), addend=neg(add)), wadd), (L, base, "negative fused")
-        monkeypatch.setenv("LOLHIP_KEYSWITCH_UNFUSED", "1")
+        gpu.debug_set("KEYSWITCH_UNFUSED", True)
         assert np.array_equal(P.keySwitch(neg(c2), base, neg(hint), addend=neg(add)), wadd), (L, base, "negative unfused")
-        monkeypatch.delenv("LOLHIP_KEYSWITCH_UNFUSED")
+        gpu.debug_set("KEYSWITCH_UNFUSED", False)
 
 
 @pytest.mark.gpu

@@ -26,6 +26,8 @@ int main(int argc, char** argv){
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run=[&]()->int{ if(!strcmp(op,"crt")) return lolhip_crt_batch(P,0,a,B); if(!strcmp(op,"crtinv")) return lolhip_crtinv_batch(P,0,a,B);
     if(!strcmp(op,"l")) return lolhip_l_batch(P,0,a,B); if(!strcmp(op,"mulgpow")) return lolhip_mulgpow_batch(P,0,a,B); if(!strcmp(op,"divgdec")) return lolhip_divgdec_batch(P,0,a,B);
+    if(!strcmp(op,"copy0")) return lolhip_copy_slab(0,c,a,(int64_t)cnt*8,0); if(!strcmp(op,"copy1")) return lolhip_copy_slab(0,c,a,(int64_t)cnt*8,1);
+    if(!strcmp(op,"mul")) return lolhip_mul_batch(P,0,a,b,B);
     if(!strcmp(op,"roundtrip")){ int r=lolhip_crt_batch(P,0,a,B); return r? r: lolhip_crtinv_batch(P,0,a,B);} return lolhip_polymul_batch(P,0,c,a,b,B); };
   unsigned long long* dst = nullptr; size_t nw = (size_t)B*T*64; 
   typedef int (*setfn)(unsigned long long*); setfn sf = (setfn)dlsym(RTLD_DEFAULT, "lolhip_debug_set_stamps");
@@ -33,7 +35,7 @@ int main(int argc, char** argv){
   for(int i=0;i<2;i++) if((rc=run())){ printf("run rc=%d\n",rc); return 1; }
   CK(hipDeviceSynchronize()); CK(hipEventRecord(e0,0)); for(int i=0;i<iters;i++) run(); CK(hipEventRecord(e1,0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
-  double bytes = (!strcmp(op,"polymul")?3.0:(!strcmp(op,"roundtrip")?4.0:2.0))*cnt*8;
+  double bytes = ((!strcmp(op,"polymul")||!strcmp(op,"mul"))?3.0:(!strcmp(op,"roundtrip")?4.0:2.0))*cnt*8;
   if(sf){ run(); CK(hipDeviceSynchronize()); int wpb = (n/16>=256? n/16:256)/64; size_t nwv=(size_t)((B*T*(n/16>=256?1:1)))*wpb; std::vector<unsigned long long> hs(nwv*32);
     CK(hipMemcpy(hs.data(),dst,nwv*32*8,hipMemcpyDeviceToHost)); double sum[32]={0}; long cnt[32]={0}; int last=-1; 
     for(size_t w=0;w<nwv;w++){ int prev=-1; for(int i=0;i<32;i++){ if(hs[w*32+i]==0) continue; if(prev>=0){ sum[i]+= (double)(hs[w*32+i]-hs[w*32+prev]); cnt[i]++; } prev=i; } }
