@@ -24,6 +24,10 @@ struct Pow2Launch {
 // mode 0 = crt, 1 = crtInv, 2 = fused poly-mul
 hipError_t launch_pow2(const Pow2Launch& a, int mode);
 
+// mode 2 only: the persistent, LDS-DMA-pipelined fused poly-mul of the 32-bit classes (pow2_pipe.hip)
+bool pow2_pipe_ok(const Pow2Launch& a, bool forced);
+hipError_t launch_pow2_pipe(const Pow2Launch& a);
+
 // fused key switch (m = 2^k, 32-bit arithmetic class, two hint coefficients)
 struct KeySwitchLaunch {
   hipStream_t stream;

@@ -25,6 +25,8 @@ namespace lolhip {
 LOLHIP_POW2_EXTERN(0) LOLHIP_POW2_EXTERN(1) LOLHIP_POW2_EXTERN(2) LOLHIP_POW2_EXTERN(3) LOLHIP_POW2_EXTERN(4)
 #undef LOLHIP_POW2_EXTERN
 template <int AR> static hipError_t launch_pow2_class(const Pow2Launch& a, int mode) {
+  // large single-modulus 32-bit poly-mul batches: the persistent, DMA-pipelined kernel (pow2_pipe.hip)
+  if (mode == 2 && !sw(SW_NO_PIPE) && pow2_pipe_ok(a, sw(SW_FORCE_PIPE))) return launch_pow2_pipe(a);
   // one modulus and 16-byte-aligned slabs: the variant that moves 16 bytes per lane
   const uintptr_t al = (uintptr_t)a.y | (mode == 2 ? ((uintptr_t)a.a | (uintptr_t)a.b) : 0);
   const bool t1 = a.T == 1 && (al & 15) == 0 && !pow2_no_t1();

@@ -145,7 +145,7 @@ void plan_free_device(Plan& P);
 // A/B switches of the launch paths (development and tests): read ONCE from the environment
 // (LOLHIP_<NAME>) into atomics; tests flip them through lolhip_debug_set, never through setenv
 // (getenv racing with setenv is undefined behaviour, and plans are used from concurrent threads).
-enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_COUNT };
+enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_COUNT };
 bool sw(Switch which);
 inline bool pow2_no_t1() { return sw(SW_NO_T1); }
 

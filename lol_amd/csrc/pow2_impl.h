@@ -374,13 +374,18 @@ __device__ __forceinline__ void load_u64x2(rsrc_t r, u32 voff, u32 soff, u64& x0
   x0 = ((u64)x.y << 32) | x.x;
   x1 = ((u64)x.w << 32) | x.z;
 }
-__device__ __forceinline__ void store_u64x2(rsrc_t r, u32 voff, u32 soff, u64 x0, u64 x1) {
+// The constant part of the address goes into voffset/the 12-bit immediate, NEVER into an SGPR soffset:
+// hipcc (ROCm 7.2) pads "store of more than 8 bytes -> VALU write of its data registers" (2 wait states on
+// gfx950) only when soffset is not a register, but MI355X needs the pad in the SGPR form too — a persistent
+// loop's last store picked up the loop-bound compare's v_mov in 16 lanes (profiles/r03_store_hazard.txt;
+// tools/check_store_hazard.py audits the assembly of every translation unit for the pair).
+__device__ __forceinline__ void store_u64x2(rsrc_t r, u32 voff, u32 coff, u64 x0, u64 x1) {
   u32x4 x;
   x.x = (u32)x0; x.y = (u32)(x0 >> 32); x.z = (u32)x1; x.w = (u32)(x1 >> 32);
 #ifdef LOLHIP_ABL_NO_IO
   if (x0 != 0x1234567ull) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, voff + coff, 0, 0);
 }
 // whole-polynomial register I/O in layout A; element stride `ebytes` (= 8 T).  Layouts whose
 // register bit 0 is position bit 0 (Sched<L, true>) move pairs with 16-byte accesses.

@@ -217,6 +217,30 @@ def test_pow2_16_byte_and_8_byte_global_access(gpu, cpuref, L):
             assert np.array_equal(P.crtInv(y), want[1]), (L, q, forced)
             assert np.array_equal(P.polymul(y, z), want[2]), (L, q, forced)
         gpu.debug_set("NO_T1", False)
+        if L in (12, 13) and q < 2 ** 31:
+            # the persistent DMA-pipelined poly-mul (pow2_pipe.hip), forced at a small batch: fewer polynomials
+            # than workgroups, a ragged last round, squaring, c aliasing a
+            gpu.debug_set("FORCE_PIPE", True)
+            assert np.array_equal(P.polymul(y, z), want[2]), (L, q, "pipe")
+            assert np.array_equal(P.polymul(y, y), cpuref.polymul(R, y, y)), (L, q, "pipe square")
+            Bb = 1100 if L == 12 else 600                                # > one round of resident workgroups
+            yb, zb = R.random(rng, Bb), R.random(rng, Bb)
+            yb[3] = np.where(yb[3] > 0, yb[3] - q, 0)
+            db_, dz_ = torch.from_numpy(yb).cuda(), torch.from_numpy(zb).cuda()
+            dout = torch.empty_like(db_)
+            P.polymul(db_, dz_, out=dout)
+            gpu.debug_set("FORCE_PIPE", False)
+            gpu.debug_set("NO_PIPE", True)
+            dref = torch.empty_like(db_)
+            P.polymul(db_, dz_, out=dref)
+            gpu.debug_set("NO_PIPE", False)
+            assert torch.equal(dout, dref), (L, q, "pipe vs one-polynomial-per-workgroup kernel")
+            rows = [0, 3, 255, 256, 511, 512, 513, Bb - 1]
+            assert np.array_equal(dout[rows].cpu().numpy(), cpuref.polymul(R, yb[rows], zb[rows])), (L, q, "pipe rows")
+            gpu.debug_set("FORCE_PIPE", True)
+            P.polymul(db_, dz_, out=db_)                                  # in place
+            gpu.debug_set("FORCE_PIPE", False)
+            assert torch.equal(db_, dref), (L, q, "pipe in place")
         # slabs that are only 8-byte aligned: one int64 into a 16-byte-aligned allocation
         n = R.n
         pad_a = torch.zeros(B * n + 1, dtype=torch.int64, device="cuda")
@@ -546,14 +570,20 @@ def _sample(cpuref_fn, got, B, k=3):
     return idx
 
 
-def test_config2_full_batch(gpu, cpuref):
-    """m = 2^14, 61-bit q, batch 4096: crtInv.crt = id over the batch; poly-mul samples and
-    ring identities (commutativity, distributivity, multiplication by the constant 1)."""
+@pytest.mark.parametrize("lower,route", [(2 ** 60, "default"), (2 ** 26, "default"), (2 ** 29, "default"), (2 ** 30, "default"),
+                                         (2 ** 29, "NO_PIPE"), (2 ** 30, "NO_T1")])
+def test_config2_full_batch(gpu, cpuref, lower, route):
+    """m = 2^14, batch 4096, at the 61-bit modulus of the metric and at one modulus of every 32-bit class
+    (q = 1073872897 > 2^30 is the one where lol-cpp's CT itself is valid): crtInv.crt = id over the batch;
+    poly-mul rows at both sides of every dispatch-round boundary (1024 workgroups resident at a time; the
+    persistent kernel's 512) against the oracle; ring identities (commutativity, distributivity, unit)."""
     torch = pytest.importorskip("torch")
     m = 2 ** 14
-    q = lm.first_good_q(m, 2 ** 60)
+    q = lm.first_good_q(m, lower)
     P, R = gpu.Plan([(2, 14)], [q]), Params([(2, 14)], [q])
     B, n = 4096, R.n
+    if route != "default":
+        gpu.debug_set(route, True)
     g = torch.Generator(device="cuda"); g.manual_seed(2)
     a = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
     b = torch.randint(0, q, (B, n, 1), dtype=torch.int64, device="cuda", generator=g)
@@ -562,7 +592,7 @@ def test_config2_full_batch(gpu, cpuref):
     c = torch.empty_like(a); P.polymul(a, b, out=c)
     c2 = torch.empty_like(a); P.polymul(b, a, out=c2)
     assert torch.equal(c, c2)                                              # commutative
-    idx = [0, 1, B // 3, B - 1]
+    idx = [0, 1, 511, 512, 1023, 1024, B // 3, 2047, 2048, 3071, 3072, 3583, 3584, B - 1]
     want = cpuref.polymul(R, a[idx].cpu().numpy(), b[idx].cpu().numpy())
     assert np.array_equal(c[idx].cpu().numpy(), want)
     # (a + b) * b == a*b + b*b  (distributive), all mod q
@@ -573,7 +603,9 @@ def test_config2_full_batch(gpu, cpuref):
     one = torch.zeros_like(a); one[:, 0, :] = 1                              # scalarPow 1 (CPP.hs:413-417)
     u = torch.empty_like(a); P.polymul(a, one, out=u)
     assert torch.equal(u, a)
-    # checksum of checksums against the sampled oracle rows is covered above; sortedness n/a
+    # in place (c aliases a), and the 61-bit and 32-bit kernels agree on the batch wherever both apply
+    x = a.clone(); P.polymul(x, b, out=x)
+    assert torch.equal(x, c)
 
 
 def test_concurrent_host_threads(gpu, cpuref):

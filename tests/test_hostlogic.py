@@ -127,3 +127,17 @@ def test_compute_without_gpu_fails_loudly(lolhip):
         raw.mulRq(1, a.ctypes.data, a.ctypes.data, 3, qs.ctypes.data)
         assert raw.lolhip_last_status() == -5
         assert list(a) == [1, 2, 3]       # untouched
+
+
+def test_device_code_has_no_unpadded_wide_store(lolhip):
+    """gfx950 needs two wait states between a VMEM store of more than 8 bytes and a VALU write of its data
+    registers; hipcc (ROCm 7.2) leaves the pair unpadded when the buffer store takes its offset from an SGPR, and
+    a persistent loop then stored the loop counter in place of residues (profiles/r03_store_hazard.txt).  The
+    shipped library's device code is disassembled and audited for the pair."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_store_hazard.py"), lolhip.lib_path()],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 unpadded store-data pair(s)" in r.stdout
