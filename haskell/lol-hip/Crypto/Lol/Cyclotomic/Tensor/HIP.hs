@@ -39,7 +39,7 @@ import qualified Data.Vector.Storable as SV
 
 import Crypto.Lol.CRTrans
 import Crypto.Lol.Cyclotomic.Tensor
-import Crypto.Lol.Cyclotomic.Tensor.CPP            (CT)
+import Crypto.Lol.Cyclotomic.Tensor.CPP            (CT, toVec, fromVec)   -- the two exports of ../../../../lol-cpp-exports.patch
 import Crypto.Lol.Cyclotomic.Tensor.CPP.Backend    (Dispatch, ZqTuple, getModuli, numComponents)
 import Crypto.Lol.Cyclotomic.Tensor.HIP.Backend
 import Crypto.Lol.Prelude                          as LP
@@ -81,10 +81,8 @@ onGPUMaybe op cpu (HT x) = case planOf (Proxy :: Proxy '(m, r)) of
 
 -- CT <-> storable vector.  lol-cpp exports CT abstractly; these two are the only additions the
 -- lol-cpp package needs for this backend (its CT' newtype unwrapped): `unCT . toCT'` and `CT . CT'`.
-toVec :: (TElt CT r) => CT m r -> SV.Vector r
-toVec = error "lol-cpp: export (toVec :: CT m r -> Vector r)   [CPP.hs:86-116: unCT after toCT]"
-fromVec :: (TElt CT r) => SV.Vector r -> CT m r
-fromVec = error "lol-cpp: export (fromVec :: Vector r -> CT m r) [CPP.hs:86-96: CT . CT']"
+-- toVec / fromVec (CT m r <-> the Storable coefficient vector) come from lol-cpp once lol-cpp-exports.patch is applied:
+-- the constructors of CT are private to CPP.hs (CPP.hs:33,86-96).
 
 instance Tensor HT where
 

@@ -286,15 +286,20 @@ template <int AR> __device__ __forceinline__ VT<AR> from_i64(i64 x, const QKT<AR
   if constexpr (AR >= 2) return (u32)x + (k.q & (u32)(x >> 63));
   else return canon_in(x, k.q);
 }
-// the same on the way INTO a forward transform: the 64-bit lazy class takes any value in [0,8q), and
-// x + 4q is in (3q,5q) for every x in (-q,q): one v_lshl_add_u64 instead of a sign test and a masked add
+// the same on the way INTO a forward transform, whose lazy range takes more than [0,q): one instruction.
+// 64-bit class: any value in [0,8q), and x + 4q is in (3q,5q) for every x in (-q,q) (one v_lshl_add_u64 instead
+// of a sign test and a masked add).  32-bit classes: x + q is in (0,2q), inside [0,2q) (class 3), [0,4q) (class 2)
+// and the wide range of class 4 (inputs below 2q: 2q + 14 * 2q = 30q < 2^32 for q < 2^27).
 template <int AR> __device__ __forceinline__ VT<AR> from_i64_fwd(i64 x, const QKT<AR>& k) {
   if constexpr (AR == 1) return add64u((u64)x, k.q4);
+  else if constexpr (AR >= 2) return (u32)x + k.q;
   else return from_i64<AR>(x, k);
 }
-// and into an inverse transform (range [0,4q)): x + 2q is in (q,3q)
+// and into an inverse transform: 64-bit class range [0,4q): x + 2q is in (q,3q); classes 2 and 4 [0,2q): x + q;
+// class 3's inverse works on canonical values
 template <int AR> __device__ __forceinline__ VT<AR> from_i64_inv(i64 x, const QKT<AR>& k) {
   if constexpr (AR == 1) return add64u((u64)x, k.q2);
+  else if constexpr (AR == 2 || AR == 4) return (u32)x + k.q;
   else return from_i64<AR>(x, k);
 }
 // the operand of the fused poly-mul that waits in registers: canonical in the 64-bit classes; in the
@@ -492,7 +497,12 @@ __device__ __forceinline__ void tw_fetch(LevelTwT<V>& t, const TwCtxT<V>& tw, in
     if (level_tab<A, K>.slot[e] == ord && (HALF < 0 || ord / (8 / LOLHIP_LEVEL_PARTS) == HALF)) {
       const int cidx = level_tab<A, K>.cidx[e];
       if constexpr (tw_uniform<A, K>()) {
-        t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
+        // through the CONSTANT address space: a uniform load from it is an s_load whatever else the kernel does.
+        // As a plain global load hipcc demotes it to a per-lane vector load as soon as it cannot prove the
+        // table unclobbered (seen in pow2_pipe.hip, where it then queued behind the LDS-DMA in vmcnt order)
+        typedef const __attribute__((address_space(4))) V* cptr_t;
+        const cptr_t cp = (cptr_t)(sp + 2 * cidx);
+        t.w[ord] = cp[0]; t.wp[ord] = cp[1];
       } else if constexpr (A.ntb + R >= TWL_MIN_L && (2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
         const V* lp = tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1)));
         if constexpr (sizeof(V) == 8) { const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
@@ -722,8 +732,16 @@ __device__ __forceinline__ int fresh(int x) {
   return x;
 }
 
-template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false, bool W16 = false>
-__device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk) {
+// The forward transform's vector-memory twiddles (the second lane-swap level and the levels after the
+// cross-wave exchange: tables of 4 KiB and more, L2-served) may be supplied by the CALLER through a provider TOP
+// with members l10, g[R] and wait_l10() / wait_g(), called right before the first use.  vmcnt retires in issue
+// order: a kernel that keeps an LDS-DMA in flight under a transform (pow2_pipe.hip) fetches these BEFORE it
+// issues the DMA, or the first such twiddle waits for the whole DMA to land.
+struct NoTop {};
+template <int AR, int L, Lay PREV, int SB = 0, bool LEAN = false, bool W16 = false, typename TOP = NoTop>
+__device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const TwCtxT<VT<AR>>& tw, int tau_in, const QKT<AR>& qk,
+                                              TOP* pre = nullptr) {
+  constexpr bool PRE = !std::is_same_v<TOP, NoTop>;
   using LevelTw = LevelTwT<VT<AR>>;
   using S = Sched<L, W16>;
   {   // W0: levels 1..4
@@ -752,7 +770,11 @@ __device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const
       transpose_get<S::w0(), A, false>(v, lds, tau);
       levels4_jit<AR, A, S::W1_K0>(v, tw, xthr<A>(tau), qk);
       if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level_jit<AR, false, S::w1a(), 3>(v, tw, xthr<S::w1a()>(tau), qk); }
-      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level_jit<AR, false, S::w1b(), 2>(v, tw, xthr<S::w1b()>(tau), qk); }
+      if constexpr (S::NSWAP >= 2) {
+        lane_swap<5, 2>(v);
+        if constexpr (PRE) { pre->wait_l10(); level<AR, false, S::w1b(), 2>(v, pre->l10, tw, qk); }
+        else level_jit<AR, false, S::w1b(), 2>(v, tw, xthr<S::w1b()>(tau), qk);
+      }
     } else {
       LevelTw t[R];
       transpose_put<S::w0(), A, false>(v, lds, tau);
@@ -767,9 +789,13 @@ __device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const
       if constexpr (S::NSWAP >= 1) tw_fetch<false, S::w1a(), 3>(ua, tw, xthr<S::w1a()>(tau));
       level<AR, false, A, 3>(v, t[3], tw, qk);
       LH_STAMP(SB + 5);
-      if constexpr (S::NSWAP >= 2) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
+      if constexpr (S::NSWAP >= 2 && !PRE) tw_fetch<false, S::w1b(), 2>(ub, tw, xthr<S::w1b()>(tau));
       if constexpr (S::NSWAP >= 1) { lane_swap<4, 3>(v); level<AR, false, S::w1a(), 3>(v, ua, tw, qk); }
-      if constexpr (S::NSWAP >= 2) { lane_swap<5, 2>(v); level<AR, false, S::w1b(), 2>(v, ub, tw, qk); }
+      if constexpr (S::NSWAP >= 2) {
+        lane_swap<5, 2>(v);
+        if constexpr (PRE) { pre->wait_l10(); level<AR, false, S::w1b(), 2>(v, pre->l10, tw, qk); }
+        else level<AR, false, S::w1b(), 2>(v, ub, tw, qk);
+      }
       LH_STAMP(SB + 6);
     }
   }
@@ -777,7 +803,13 @@ __device__ __forceinline__ void fwd_transform(VT<AR> (&v)[E], VT<AR>* lds, const
     constexpr Lay A = S::g();
     const int tau = fresh(tau_in);
     transpose_put<S::wave_end(), A, false>(v, lds, tau);   // writes stay inside the wave's own block
-    if constexpr (LEAN) {
+    if constexpr (PRE) {
+      transpose_get<S::wave_end(), A, true>(v, lds, tau);  // barrier, then read across blocks
+      LH_STAMP(SB + 7);
+      pre->wait_g();
+      levels4<AR, false, A, S::G_K0>(v, pre->g, tw, qk);
+      LH_STAMP(SB + 8);
+    } else if constexpr (LEAN) {
       transpose_get<S::wave_end(), A, true>(v, lds, tau);  // barrier, then read across blocks
       levels4_jit<AR, A, S::G_K0>(v, tw, xthr<A>(tau), qk);
     } else {

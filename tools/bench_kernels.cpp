@@ -39,6 +39,9 @@ int main(int argc, char** argv){
   if(sf){ run(); CK(hipDeviceSynchronize()); int wpb = (n/16>=256? n/16:256)/64; size_t nwv=(size_t)((B*T*(n/16>=256?1:1)))*wpb; std::vector<unsigned long long> hs(nwv*32);
     CK(hipMemcpy(hs.data(),dst,nwv*32*8,hipMemcpyDeviceToHost)); double sum[32]={0}; long cnt[32]={0}; int last=-1; 
     for(size_t w=0;w<nwv;w++){ int prev=-1; for(int i=0;i<32;i++){ if(hs[w*32+i]==0) continue; if(prev>=0){ sum[i]+= (double)(hs[w*32+i]-hs[w*32+prev]); cnt[i]++; } prev=i; } }
+    { double clk=0; long nc=0; for(size_t w=0;w<nwv;w++){ unsigned long long t0=hs[w*32+26],t1=hs[w*32+27],r0=hs[w*32+28],r1=hs[w*32+29]; if(t0&&t1&&r1>r0){ clk += (double)(t1-t0)/(double)(r1-r0)*100.0; nc++; } }
+      double mt=0, mr=0; for(size_t w=0;w<nwv;w++){ unsigned long long t0=hs[w*32+26],t1=hs[w*32+27],r0=hs[w*32+28],r1=hs[w*32+29]; if(t0&&t1&&r1>r0){ mt += (double)(t1-t0); mr += (double)(r1-r0); } }
+      if(nc) printf("  in-kernel clock: %.0f MHz (s_memtime / s_memrealtime x 100 MHz, mean over %ld waves); loop lifetime per wave: %.0f ticks = %.1f us\n", clk/nc, nc, mt/nc, mr/nc/100.0); }
     if(getenv("LOLHIP_STAMP_DUMP")){ FILE* f=fopen(getenv("LOLHIP_STAMP_DUMP"),"wb"); fwrite(hs.data(),8,hs.size(),f); fclose(f); }
     for(int i=0;i<32;i++) if(cnt[i]) printf("  stamp %2d: +%8.0f cycles (avg over %ld waves)\n", i, sum[i]/cnt[i], cnt[i]); (void)last; }
   printf("%s m=%ld n=%ld T=%d B=%ld q~2^%d: %.4f ms/iter  %.3f M items/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)\n", op, mval, n, T, B, qbits, ms, B/ms/1e3, bytes/ms/1e6, bytes/ms/1e6/80.0);
