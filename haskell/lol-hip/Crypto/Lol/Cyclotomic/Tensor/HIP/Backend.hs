@@ -63,10 +63,13 @@ foreign import ccall unsafe "lolhip_ext_create"
   c_extCreate :: Ptr PlanH -> Ptr PlanH -> Ptr (Ptr ExtH) -> IO CInt
 foreign import ccall unsafe "&lolhip_ext_destroy"
   p_extDestroy :: FunPtr (Ptr ExtH -> IO ())
--- host-pointer entry points: one H2D, the kernels, one D2H on the calling thread's own stream
-foreign import ccall unsafe "lolhip_op_host"
+-- host-pointer entry points: one H2D, the kernels, one D2H on a leased stream.  They BLOCK in
+-- hipStreamSynchronize for the whole kernel time, so they are `safe` imports: an `unsafe` call would hold the
+-- capability (no other Haskell thread runs on it, GC waits) until the GPU is done.  Safe calls may migrate
+-- between OS threads; liblolhip's staging sets belong to no thread (include/lolhip.h, lolhip_thread_release).
+foreign import ccall safe "lolhip_op_host"
   c_opHost :: Ptr PlanH -> CInt -> Ptr Int64 -> Ptr Int64 -> Int64 -> IO CInt
-foreign import ccall unsafe "lolhip_ext_host"
+foreign import ccall safe "lolhip_ext_host"
   c_extHost :: Ptr ExtH -> CInt -> Ptr Int64 -> Ptr Int64 -> Int64 -> IO CInt
 
 -- | One plan per (prime powers, moduli), created on first use and kept for the life of the
@@ -93,13 +96,23 @@ planFor pps qs = unsafePerformIO $ modifyMVar planCache $ \m ->
 planHasCRT :: Plan -> Bool
 planHasCRT p = unsafePerformIO $ withForeignPtr p $ fmap (/= 0) . c_planHasCRT
 
--- | Tables for the ring extension m | m'; both plans must share their moduli.
+-- | Tables for the ring extension m | m'; both plans must share their moduli.  Cached like the plans (which
+-- live as long as the process, so their addresses identify them): building one costs several hipMalloc and
+-- blocking copies of index tables, and twace/embed/coeffs ask for it on EVERY element operation.
+{-# NOINLINE extCache #-}
+extCache :: MVar (M.Map (Ptr PlanH, Ptr PlanH) Ext)
+extCache = unsafePerformIO $ newMVar M.empty
+
 extFor :: Plan -> Plan -> Ext
-extFor lo hi = unsafePerformIO $
-  withForeignPtr lo $ \plo -> withForeignPtr hi $ \phi -> alloca $ \out -> do
-    rc <- c_extCreate plo phi out
-    when (rc /= ok) $ error $ "lolhip_ext_create: status " ++ show rc
-    peek out >>= newForeignPtr p_extDestroy
+extFor lo hi = unsafePerformIO $ modifyMVar extCache $ \m ->
+  withForeignPtr lo $ \plo -> withForeignPtr hi $ \phi ->
+    case M.lookup (plo, phi) m of
+      Just e  -> return (m, e)
+      Nothing -> alloca $ \out -> do
+        rc <- c_extCreate plo phi out
+        when (rc /= ok) $ error $ "lolhip_ext_create: status " ++ show rc
+        e <- peek out >>= newForeignPtr p_extDestroy
+        return (M.insert (plo, phi) e m, e)
 
 -- | In-place operation on a thawed copy, as CT does (CPP.hs:325-337): Haskell owns the memory,
 -- the library never keeps the pointer.  @b@ polynomials of @n*T@ Int64 residues each.

@@ -257,11 +257,12 @@ enum {
   LOLHIP_EXT_EMBED_DEC = 3, LOLHIP_EXT_EMBED_CRT = 4, LOLHIP_EXT_COEFFS = 5
 };
 LOLHIP_API int lolhip_ext_host(const lolhip_ext *x, int op, int64_t *out, const int64_t *in, int64_t B);
-/* The host-pointer calls (and the drop-in symbols, which go through them) keep per host thread and
- * device one stream, a pinned staging area and two device buffers, grown on demand: the steady
- * state of a call is memcpy, H2D, kernels, D2H and a wait on that thread's stream — no allocation,
- * no device-wide synchronisation.  This frees the calling thread's set (optional; e.g. before a
- * worker thread exits). */
+/* The host-pointer calls (and the drop-in symbols, which go through them) check a staging set — one stream, a
+ * pinned staging area and two device buffers, grown on demand — out of a process-wide pool for the duration of
+ * the call: the steady state of a call is memcpy, H2D, kernels, D2H and a wait on that set's stream — no
+ * allocation, no device-wide synchronisation.  The pool holds as many sets as calls have run concurrently; sets
+ * belong to no thread, so exiting worker threads leave nothing behind.  This frees every idle set (optional;
+ * e.g. to hand the memory back between phases).  The name dates from round 2, when the sets were per thread. */
 LOLHIP_API void lolhip_thread_release(void);
 
 /* --- wire format: Lol's protobuf ring elements, host side -------

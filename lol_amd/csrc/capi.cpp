@@ -706,11 +706,14 @@ int lolhip_twace_crt_batch(const lolhip_ext* x, void* s, int64_t* lo_out, const 
 
 namespace {
 
-// Per host thread and device: one stream, one pinned staging area and two device buffers, grown on
-// demand and kept — the steady state of a host-pointer call is memcpy -> H2D -> kernels -> D2H ->
-// hipStreamSynchronize on the thread's own stream: no hipMalloc/hipFree, no device-wide
-// synchronisation, nothing shared with other threads (what the reference's callers need:
-// CPP.hs:325-337 thaws a fresh vector and calls one tensor*Rq per ring operation).
+// A staging set = one stream, one pinned staging area and two device buffers, grown on demand and kept.
+// A host-pointer call CHECKS ONE OUT of a process-wide pool for its duration and returns it (StageLease):
+// the steady state is memcpy -> H2D -> kernels -> D2H -> hipStreamSynchronize on that set's own stream — no
+// hipMalloc/hipFree, no device-wide synchronisation, nothing shared between concurrent calls (what the
+// reference's callers need: CPP.hs:325-337 thaws a fresh vector and calls one tensor*Rq per ring operation).
+// The pool holds as many sets as calls have ever run at the same time; nothing belongs to a thread, so a worker
+// thread that exits (a GHC safe-FFI worker, a thread pool) leaves nothing behind.  (Round 2 kept the sets in
+// thread_local storage without a destructor: every exiting thread leaked a stream, pinned memory and HBM.)
 struct HostStage {
   int dev = -1;
   hipStream_t stream = nullptr;
@@ -744,27 +747,55 @@ struct HostStage {
     *this = HostStage();
   }
 };
-thread_local std::vector<HostStage> g_stage;     // one entry per device this thread has used
+struct StagePool {
+  std::mutex mu;
+  std::vector<HostStage*> idle;
+  HostStage* acquire() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < idle.size(); ++i)
+        if (idle[i]->dev == dev) { HostStage* h = idle[i]; idle.erase(idle.begin() + (long)i); return h; }
+    }
+    HostStage* h = new HostStage();
+    h->dev = dev;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
+    return h;
+  }
+  void give_back(HostStage* h) { std::lock_guard<std::mutex> g(mu); idle.push_back(h); }
+  void release_all() {
+    std::vector<HostStage*> all;
+    { std::lock_guard<std::mutex> g(mu); all.swap(idle); }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (HostStage* h : all) { (void)hipSetDevice(h->dev); h->release(); delete h; }
+    if (cur >= 0) (void)hipSetDevice(cur);
+  }
+};
+StagePool& stage_pool() { static StagePool* pool = new StagePool(); return *pool; }   // never destroyed: no HIP call at process teardown
 
-HostStage* host_stage() {
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  for (HostStage& h : g_stage) if (h.dev == dev) return &h;
-  HostStage h;
-  h.dev = dev;
-  if (hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  g_stage.push_back(h);
-  return &g_stage.back();
-}
+// one call's hold on a staging set.  `enqueued` = something of this call may be in flight on the set's stream:
+// every exit then waits for the stream first, so the next user never copies into a pinned area a transfer is
+// still reading.
+struct StageLease {
+  HostStage* h;
+  bool enqueued = false;
+  StageLease() : h(stage_pool().acquire()) {}
+  ~StageLease() {
+    if (!h) return;
+    if (enqueued) (void)hipStreamSynchronize(h->stream);
+    stage_pool().give_back(h);
+  }
+  StageLease(const StageLease&) = delete;
+  StageLease& operator=(const StageLease&) = delete;
+};
 
 }  // namespace
 
 extern "C" {
 
-void lolhip_thread_release(void) {
-  for (HostStage& h : g_stage) h.release();
-  g_stage.clear();
-}
+void lolhip_thread_release(void) { stage_pool().release_all(); }
 
 int lolhip_op_host(const lolhip_plan* p, int op, int64_t* y, const int64_t* b, int64_t B) {
   int rc = need_device(p); if (rc) return rc;
@@ -775,13 +806,15 @@ int lolhip_op_host(const lolhip_plan* p, int op, int64_t* y, const int64_t* b, i
   if (bytes == 0) return LOLHIP_OK;
   const bool two = (op == LOLHIP_OP_MUL || op == LOLHIP_OP_POLYMUL);
   if (two && !b) return LOLHIP_ERR_INVALID;
-  HostStage* h = host_stage();
+  StageLease lease;
+  HostStage* h = lease.h;
   if (!h) return LOLHIP_ERR_HIP;
   if (!h->grow_pinned(two ? 2 * bytes : bytes) || !h->grow_dev(0, bytes) || (two && !h->grow_dev(1, bytes))) return LOLHIP_ERR_HIP;
   hipStream_t s = h->stream;
   int64_t* dy = (int64_t*)h->d[0];
   int64_t* db = (int64_t*)h->d[1];
   std::memcpy(h->pinned, y, bytes);
+  lease.enqueued = true;                       // from here on every return waits for the stream (StageLease)
   if (hipMemcpyAsync(dy, h->pinned, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
   if (two) {
     std::memcpy(h->pinned + bytes, b, bytes);
@@ -803,6 +836,7 @@ int lolhip_op_host(const lolhip_plan* p, int op, int64_t* y, const int64_t* b, i
   }
   if (!rc && hipMemcpyAsync(h->pinned, dy, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
   if (hipStreamSynchronize(s) != hipSuccess) return LOLHIP_ERR_HIP;   // also on error: nothing of ours stays in flight
+  lease.enqueued = false;
   if (rc) return rc;
   std::memcpy(y, h->pinned, bytes);
   return LOLHIP_OK;
@@ -817,13 +851,16 @@ int lolhip_ext_host(const lolhip_ext* x, int op, int64_t* out, const int64_t* in
   const size_t bin = sizeof(int64_t) * (size_t)(B * (to_hi ? x->X.host.phi : x->X.host.phi2) * T);
   const size_t bout = sizeof(int64_t) * (size_t)(B * ((to_hi || op == LOLHIP_EXT_COEFFS) ? x->X.host.phi2 : x->X.host.phi) * T);
   if (bout == 0) return LOLHIP_OK;
-  HostStage* h = host_stage();
+  if (op < LOLHIP_EXT_TWACE_POWDEC || op > LOLHIP_EXT_COEFFS) return LOLHIP_ERR_INVALID;
+  StageLease lease;
+  HostStage* h = lease.h;
   if (!h) return LOLHIP_ERR_HIP;
   if (!h->grow_pinned(bin > bout ? bin : bout) || !h->grow_dev(0, bin) || !h->grow_dev(1, bout)) return LOLHIP_ERR_HIP;
   hipStream_t s = h->stream;
   int64_t* di = (int64_t*)h->d[0];
   int64_t* dout = (int64_t*)h->d[1];
   std::memcpy(h->pinned, in, bin);
+  lease.enqueued = true;
   if (hipMemcpyAsync(di, h->pinned, bin, hipMemcpyHostToDevice, s) != hipSuccess) return LOLHIP_ERR_HIP;
   int rc;
   switch (op) {
@@ -837,6 +874,7 @@ int lolhip_ext_host(const lolhip_ext* x, int op, int64_t* out, const int64_t* in
   }
   if (!rc && hipMemcpyAsync(h->pinned, dout, bout, hipMemcpyDeviceToHost, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
   if (hipStreamSynchronize(s) != hipSuccess) return LOLHIP_ERR_HIP;
+  lease.enqueued = false;
   if (rc) return rc;
   std::memcpy(out, h->pinned, bout);
   return LOLHIP_OK;

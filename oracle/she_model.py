@@ -200,3 +200,63 @@ class SHE:
         she2.s_crt = eng2.crt(she2.s)
         c = [eng2.l(self.e.rescaleDropFirst(self.e.lInv(ct["c"][0])))] + [self.e.rescaleDropFirst(x) for x in ct["c"][1:]]
         return {"enc": "MSD", "k": ct["k"], "l": ct["l"], "c": c}, she2
+
+
+# =============================================================================================
+# ring tunnelling (SymmSHE.hs:500-570, Linear.hs:55-119) with r' = r, s' = s (so e' = e)
+# =============================================================================================
+class CpuTunnelEngine:
+    """The operations between E = O_e, R = O_r and S = O_s the tunnel needs, from the CPU oracle
+    (same method names as TunnelEngine over lol_amd.Ext in tests/test_she_properties.py)."""
+
+    def __init__(self, cpu: CpuRef, PE: Params, PR: Params, PS: Params):
+        self.cpu, self.PE, self.PR, self.PS = cpu, PE, PR, PS
+
+    def evalLin(self, r_dec, ys_crt): return sr.evallin(self.cpu, self.PE, self.PR, self.PS, r_dec, ys_crt)
+    def tunnel(self, c0_dec, c1_pow, ys_crt, hints, base): return sr.tunnel(self.cpu, self.PE, self.PR, self.PS, c0_dec, c1_pow, ys_crt, hints, base)
+
+
+def ks_hint(she: SHE, value_crt, base):
+    """ksHint skout r (SymmSHE.hs:262-300): hint_j = const (g_j r) + [c1_j (-s) + e_j, c1_j], CRT basis, [L][2][n][T].
+    value_crt [1][n][T]: the element the hint lets one multiply by, CRT basis, under she's secret key."""
+    g = she.e.gadget(base)
+    rows = []
+    for j in range(g.shape[0]):
+        c1 = she.uniform(1)
+        err = she.e.crt(she.small_dec(1))
+        gv = np.ascontiguousarray(np.stack([(value_crt[..., t].astype(object) * int(g[j, t]) % q).astype(np.int64) for t, q in enumerate(she.qs)], axis=-1))
+        h0 = she.add(she.add(gv, err), she.sub(np.zeros_like(c1), she.e.mul(c1, she.s_crt)))
+        rows.append(np.stack([h0[0], c1[0]]))
+    return np.ascontiguousarray(np.stack(rows))
+
+
+def tunnel_hint(she_in: SHE, she_out: SHE, xeng, rel_pow_index, f_vals_p, base):
+    """tunnelHint f skout skin (SymmSHE.hs:531-545).  f is given by its values f_vals_p [rel][n_S] (residues mod p,
+    powerful basis of S) on the relative decoding basis of R/E (linearDec, Linear.hs:65-72).
+      f'  = lift f      : liftPow of every value (Linear.hs:104-107), then reduced mod q -> ys (CRT basis of S_q)
+      ps  = powBasis    : the relative powerful basis of R/E, p_i = the powerful-basis unit vector of R at
+                          rel_pow_index[i] (Tensor.hs:472-477 pairs index (i, 0) with it)
+      comps_i = evalLin f' (s_in * p_i);  hints_i = ksHint skout comps_i
+    Returns (ys_crt [rel][n_S][T], hints [rel][L][2][n_S][T])."""
+    p = she_in.p
+    v = np.asarray(f_vals_p).astype(object) % p
+    v = np.where(2 * v < p, v, v - p)                                    # liftPow: centred representatives
+    ys_crt = she_out.e.crt(she_out.reduce(v))                            # [rel][n_S][T]
+    hints = []
+    for i, idx in enumerate(rel_pow_index):
+        pi = np.zeros((1, she_in.n, she_in.T), dtype=np.int64)
+        pi[0, idx, :] = 1
+        sp_dec = she_in.e.lInv(she_in.rmul(she_in.s, pi))                # s_in * p_i, decoding basis of R
+        comp_crt = xeng.evalLin(sp_dec, ys_crt)                          # [1][n_S][T], CRT basis of S
+        hints.append(ks_hint(she_out, comp_crt, base))
+    return ys_crt, np.ascontiguousarray(np.stack(hints))
+
+
+def tunnel(she_in: SHE, xeng, ys_crt, hints, base, ct):
+    """tunnel (SymmSHE.hs:549-570): toMSD . absorbGFactors (a ciphertext with k = 0 here), c0' = evalLin f'q c0,
+    c1' = sum_i switch hints_i (embed (coeffsPow_i c1)) — the fused lolhip_tunnel_batch / its restatement."""
+    ct = she_in.toMSD(ct)
+    assert ct["k"] == 0 and len(ct["c"]) == 2
+    c0_dec = she_in.e.lInv(ct["c"][0])
+    out = xeng.tunnel(c0_dec, ct["c"][1], ys_crt, hints, base)           # [2][B][n_S][T], CRT basis of S
+    return {"enc": "MSD", "k": 0, "l": ct["l"], "c": out}                # still in the CRT basis: the caller converts

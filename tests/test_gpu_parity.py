@@ -608,6 +608,46 @@ def test_config2_full_batch(gpu, cpuref, lower, route):
     assert torch.equal(x, c)
 
 
+def test_short_lived_host_threads_leave_nothing_behind(gpu, cpuref):
+    """Host-pointer calls from many short-lived OS threads (a GHC safe-FFI worker pool, a thread pool): staging sets
+    are leased from a process-wide pool per call, so HBM in use after 48 such threads equals HBM in use after the
+    first, every result is the oracle's, and lolhip_thread_release gives the pooled memory back."""
+    import threading
+    torch = pytest.importorskip("torch")
+    pps, qs = [(2, 12)], [lm.first_good_q(2 ** 12, 2 ** 40)]
+    P, R = gpu.Plan(pps, qs), Params(pps, qs)
+    rng = np.random.default_rng(5)
+    y = R.random(rng, 64)                         # 1 MiB per operand: the staging buffers are visible in mem_get_info
+    want = cpuref.crt(R, y)
+    gpu.lib().lolhip_thread_release()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    bad = []
+
+    def work():
+        try:
+            if not np.array_equal(P.crt(y), want):
+                bad.append("mismatch")
+        except Exception as e:                     # noqa: BLE001
+            bad.append(repr(e))
+
+    t = threading.Thread(target=work); t.start(); t.join()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 < free0                            # the pool kept the first call's buffers
+    for _ in range(48):
+        t = threading.Thread(target=work); t.start(); t.join()
+    assert not bad, bad[:3]
+    assert torch.cuda.mem_get_info()[0] == free1    # ... and 48 more threads added nothing
+    # concurrent calls each get their own set; afterwards at most that many are pooled
+    ts = [threading.Thread(target=work) for _ in range(6)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not bad, bad[:3]
+    gpu.lib().lolhip_thread_release()
+    free2 = torch.cuda.mem_get_info()[0]
+    assert free2 > free1                            # the pooled buffers are handed back ...
+    assert free0 - free2 <= 16 << 20                # ... all of them (the runtime keeps a few MiB of its own per new stream)
+
+
 def test_concurrent_host_threads(gpu, cpuref):
     """The reference is non-reentrant (process-global modulus, types.h:59).  Here four host
     threads drive their own plans (different rings and moduli, one of them the mixed-radix path
