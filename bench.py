@@ -116,6 +116,11 @@ def _leg(ms, items, alg_bytes, **extra):
     return d
 
 
+def _check_rc(rc):
+    if rc != 0:
+        raise SystemExit(f"bench: liblolhip returned status {rc}")
+
+
 def _good_qs(lol_amd, m, lower, T):
     out, lo = [], lower
     for _ in range(T):
@@ -149,8 +154,14 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
     slab = B * n * T * 8
     out = {}
     # ---- config 2's launch shape in the other arithmetic classes -----------------------------
-    # the practical ceiling beside the 8 TB/s datasheet peak: a device-to-device copy of the same slab
-    out["hbm_copy"] = _leg(timed(lambda: c.copy_(a)), B, 2 * slab, workload="torch copy_ of the 256 MiB slab (read + write), same stream")
+    # the yardstick beside the 8 TB/s datasheet peak: liblolhip's own read-once/write-once copy of the same slab,
+    # 16 bytes per lane (lolhip_copy_slab); torch's copy_ beside it.  Every HBM-bound leg below also carries
+    # `vs_copy` = its algorithmic GB/s over this copy's.  (An IN-PLACE transform re-writes the lines it has just
+    # read and can beat an out-of-place copy: crt_27bit does.)
+    Lc = lol_amd.lib()
+    out["hbm_copy"] = _leg(timed(lambda: _check_rc(Lc.lolhip_copy_slab(st, c.data_ptr(), a.data_ptr(), slab, 0))), B, 2 * slab,
+                           workload="lolhip_copy_slab: 16 B per lane, one 16 KiB tile per workgroup, 256 MiB slab (read + write), same stream")
+    out["hbm_copy_torch"] = _leg(timed(lambda: c.copy_(a)), B, 2 * slab, workload="torch copy_ of the same slab")
     c.copy_(a)
     out["crt_61bit"] = _leg(timed(lambda: plan.crt(c, stream=st)), B, 2 * slab)
     y = torch.empty_like(a)
@@ -184,7 +195,19 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
             P3.crtInv(o, stream=st)
     ms = timed(ring_product, iters=5, warm=1)
     out["c3_ctmul_pow"] = _leg(ms, B3, 7 * slab3, workload="the same from and to the powerful basis: 4 crt + product + 3 crtInv (8 launches)")
-    del ops, outs, P3
+    # config 3's ring and moduli through the key switch (SymmSHE.hs:361-371): 64-bit moduli take the three-launch path
+    # (decompose -> L*B crt -> knapsack); B = 64 ciphertexts keeps the digit slab at 1 GiB
+    B3k = 64
+    c2k = rnd(qs3, B3k, P3.n)
+    addk = torch.stack([rnd(qs3, B3k, P3.n) for _ in range(2)])
+    resk = torch.empty_like(addk)
+    Ldk = P3.decomposeLen(0)
+    hintk = rnd(qs3, Ldk, 2, P3.n)
+    workk = torch.empty((Ldk, B3k, P3.n, P3.T), dtype=torch.int64, device="cuda")
+    ms = timed(lambda: _check_rc(L.lolhip_keyswitch_batch(P3._h, st, ptr(c2k), 0, ptr(hintk), 2, ptr(addk), ptr(resk), ptr(workk), B3k)), iters=5, warm=1)
+    out["c3_keyswitch_trivgad"] = _leg(ms, B3k, 5 * B3k * P3.n * P3.T * 8, digits=Ldk,
+                                       workload="keySwitchQuadCirc body at m=2^15 T=4 59-bit, TrivGad, B=64: three launches (no fused kernel for 64-bit moduli)")
+    del ops, outs, P3, c2k, addk, resk, hintk, workk
     # ---- config 4: m = 15015, batch 1024, q just above 2^30 and just above 2^60 ---------------
     pps4 = lol_amd.factor_pps(15015)
     for name, lower in (("q30", 1 << 30), ("q60", 1 << 60)):
@@ -232,6 +255,10 @@ def secondary(lol_amd, torch, plan, a, c, B, n, T, stream):
     ms = timed(lambda: X.embedCRT(lo, out=hi, stream=st))
     out["c5_embed_crt"] = _leg(ms, B5, (P5.n + P5h.n) * 2 * 8 * B5, workload="embedCRT 2048 -> 14336 (Extension.hs:81-85), T=2 B=8192")
     del X, lo, hi, P5h, P5
+    copy_gbps = out["hbm_copy"]["alg_GBps"]
+    for k, v in out.items():
+        if isinstance(v, dict) and "alg_GBps" in v and k not in ("hbm_copy",):
+            v["vs_copy"] = round(v["alg_GBps"] / copy_gbps, 3)
     return out
 
 
@@ -541,7 +568,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "stored: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel, separate passes); not measured by this run",
-                         "kernel": "k_pow2<13,2,1> (fused crt,crt,mul,crtInv)", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "k_pow2<13,2,1,true> (fused crt,crt,mul,crtInv; 16 B per lane)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "parity_sample_ok": parity,
             "parity_note": ("bit-exact vs the pinned CPU restatement (oracle/cpu_ref.c, itself pinned on lol-cpp's golden vectors); "

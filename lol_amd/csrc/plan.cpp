@@ -156,37 +156,33 @@ static void build_crt_programs(const std::vector<PP>& pps, const Ring& R, PoolBu
       // dftTwiddle diagonals, one per DFT stage of DFT_{p^(e-1)} (crt.cpp:84-126, 459-516)
       const int e1 = e - 1;
       const i64 rts1 = rts * (p - 1);
-      auto dft_diag = [&](int ecur, i64 dim, i64 twidRuStride) -> int {
+      auto dft_diag = [&](int levels, i64 dim, i64 root_step) -> int {
         if (dim / p <= 1) return -1;
         return pool.per_comp([&](int t, std::vector<E>& o) {
           for (i64 c = 0; c < dim; ++c) {
             i64 i0 = c / p, i1 = c % p;
-            o[(size_t)c] = (i0 == 0 || i1 == 0) ? R.one(t) : ru(t, digit_rev(p, ecur - 1, i0) * i1 * twidRuStride);
+            o[(size_t)c] = (i0 == 0 || i1 == 0) ? R.one(t) : ru(t, digit_rev(p, levels - 1, i0) * i1 * root_step);
           }
         }, (size_t)dim);
+      };
+      // DFT_{p^(e-1)} = e-1 radix-p stages.  Stage j (j = 0 .. e-2) applies DFT_p to vectors of stride
+      // rts1 p^j and is followed by the diagonal of the sub-transform of size p^(e-1-j), whose entry (i0, i1)
+      // is omega_{p^e}^(digit_rev_{e-1-j}(i0) i1 p^(j+1)).  The inverse transform is the same list backwards,
+      // each diagonal (built from the inverse roots) BEFORE its butterfly stage.  (What crt.cpp:459-516 walks
+      // with running lts/rts/stride variables, in closed form.)
+      auto dft_stage = [&](int j) {
+        const i64 stride = rts1 * ipow(p, j), dim = ipow(p, e1 - j);
+        const int diag = dft_diag(e1 - j, dim, ipow(p, j + 1));
+        if (inv && diag >= 0) pb.diag(diag, stride, dim);
+        pb.dense(ST_DFTP, p, p, stride, wp_off, mat_dft);
+        if (!inv && diag >= 0) pb.diag(diag, stride, dim);
       };
       if (!inv) {
         if (p != 2) pb.dense(ST_CRTP, p, p - 1, rts, wp_off, mat_crt);
         if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
-        i64 ltsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, rtsScale = 1, twidRuStride = p;
-        int ecur = e1;
-        for (int i = 0; i < e1; ++i) {
-          const i64 rtsDim = rts1 * rtsScale;
-          pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
-          int off = dft_diag(ecur, ltsScale * p, twidRuStride);
-          if (off >= 0) pb.diag(off, rtsDim, ltsScale * p);
-          ltsScale /= p; rtsScale *= p; twidRuStride *= p; --ecur;
-        }
+        for (int j = 0; j < e1; ++j) dft_stage(j);
       } else {
-        i64 ltsScale = 1, rtsScale = e1 > 0 ? ipow(p, e1 - 1) : 0, twidRuStride = e1 > 0 ? p * ipow(p, e1 - 1) : 0;
-        int ecur = 1;
-        for (int i = 0; i < e1; ++i) {
-          const i64 rtsDim = rts1 * rtsScale, ltsScaleP = ltsScale * p;
-          int off = dft_diag(ecur, ltsScaleP, twidRuStride);
-          if (off >= 0) pb.diag(off, rtsDim, ltsScaleP);
-          pb.dense(ST_DFTP, p, p, rtsDim, wp_off, mat_dft);
-          ltsScale = ltsScaleP; rtsScale /= p; twidRuStride /= p; ++ecur;
-        }
+        for (int j = e1 - 1; j >= 0; --j) dft_stage(j);
         if (ctw_off >= 0) pb.diag(ctw_off, rts, phi);
         if (p != 2) pb.dense(ST_CRTPINV, p, p - 1, rts, wp_off, mat_crt);
       }

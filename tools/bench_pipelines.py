@@ -28,9 +28,12 @@ def rnd(gen, qs, *shape):
     return torch.stack([torch.randint(0, q, shape, dtype=torch.int64, device="cuda", generator=gen) for q in qs], dim=-1)
 
 
-def report(name, cfg, ms, items, alg_bytes):
-    print(json.dumps({"op": name, "config": cfg, "ms": round(ms, 4), "items_per_s": round(items / ms * 1e3, 1),
-                      "alg_GBps": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000, 4)}), flush=True)
+def report(name, cfg, ms, items, alg_bytes, note=None):
+    d = {"op": name, "config": cfg, "ms": round(ms, 4), "items_per_s": round(items / ms * 1e3, 1),
+         "alg_GBps": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000, 4)}
+    if note:
+        d["note"] = note
+    print(json.dumps(d), flush=True)
 
 
 def good_qs(m, lower, T):
@@ -83,7 +86,8 @@ def main():
             ms = timeit(lambda: L.lolhip_decompose_batch(P._h, st, ptr(c2), base, ptr(work), B))
             report("  decompose", f"L={Ld}", ms, B, (1 + Ld) * slab)
             ms = timeit(lambda: L.lolhip_crt_batch(P._h, st, ptr(work), Ld * B))
-            report("  crt(digits)", f"L={Ld}", ms, B * Ld, 2 * Ld * slab)
+            ic = "digit slab %d MiB: re-read from the 256 MiB Infinity Cache when it fits (not an HBM rate)" % (Ld * slab >> 20) if Ld * slab <= (256 << 20) else None
+            report("  crt(digits)", f"L={Ld}", ms, B * Ld, 2 * Ld * slab, note=ic)
             ms = timeit(lambda: L.lolhip_knapsack_batch(P._h, st, ptr(work), Ld, ptr(hint), 2, ptr(add), ptr(out), B))
             report("  knapsack", f"L={Ld} K=2", ms, B, (Ld + 4) * slab)
     # ---- rescale: drop the first of four 59-bit moduli at m = 2^15 --------------------------
@@ -115,11 +119,16 @@ def streaming(gen):
     x_lo, x_hi = rnd(gen, qs, B, lo.n), rnd(gen, qs, B, hi.n)
     o_lo, o_hi = torch.empty_like(x_lo), torch.empty_like(x_hi)
     byts = B * (lo.n + hi.n) * 2 * 8
+    # twacePowDec reads only phi(m) of the phi(m') coefficients (every 6th here, 16 bytes each: whole 64-byte sectors
+    # are fetched): compulsory traffic = n coefficients in and out, NOT the (n + n') of the other members
+    byts_twpd = B * 2 * lo.n * 2 * 8
     cfg = f"2048 -> 14336 T=2 B={B}"
-    for name, fn in (("embedPow", lambda: E.embedPow(x_lo, out=o_hi)), ("embedDec", lambda: E.embedDec(x_lo, out=o_hi)),
-                     ("embedCRT", lambda: E.embedCRT(x_lo, out=o_hi)), ("twacePowDec", lambda: E.twacePowDec(x_hi, out=o_lo)),
-                     ("twaceCRT", lambda: E.twaceCRT(x_hi, out=o_lo))):
-        report(name, cfg, timeit(fn), B, byts)
+    for name, fn, bb, note in (("embedPow", lambda: E.embedPow(x_lo, out=o_hi), byts, None), ("embedDec", lambda: E.embedDec(x_lo, out=o_hi), byts, None),
+                               ("embedCRT", lambda: E.embedCRT(x_lo, out=o_hi), byts, None),
+                               ("twacePowDec", lambda: E.twacePowDec(x_hi, out=o_lo), byts_twpd,
+                                "2 n T 8 bytes per item; the gathered 16-byte pairs sit 96 bytes apart, so the sectors fetched are 4x the bytes used"),
+                               ("twaceCRT", lambda: E.twaceCRT(x_hi, out=o_lo), byts, None)):
+        report(name, cfg, timeit(fn), B, bb, note=note)
 
 
 if __name__ == "__main__":
