@@ -9,6 +9,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
+make -s -C $R/tools || true      # the development binaries are built, never committed
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err
 echo "bench done"
