@@ -491,6 +491,25 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
     }
     return launch_keyswitch_fused(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
+  // ... and for every other index the vector interpreter takes, in its 32-bit Montgomery class (mixed_ks.hip)
+  if (!P.is_pow2 && P.mixed_cls == 2 && P.d_consts32 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
+      (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !sw(SW_KEYSWITCH_UNFUSED)) {
+    const bool fused2 = use_fused2(P);
+    const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);
+    const StageProgram& pf = fused2 ? P.prog_crt_fused : P.prog_crt;
+    if (!split2 && (fused2 || use_mixed(P, P.prog_crt))) {
+      MixedKeySwitchLaunch l;
+      l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B; l.T = P.T; l.n = P.n;
+      l.st_crt = pf.d_stages; l.n_crt = pf.nstages; l.consts32 = P.d_consts32; l.cpc = P.consts_per_comp; l.mod = P.d_mod; l.dp = d;
+      l.magic32 = 1;
+      if (base >= 2) {
+        int lg = 0;
+        while (((u64)1 << lg) < (u64)base) ++lg;
+        l.magic32 = (uint32_t)((((u64)1 << 32) * (((u64)1 << lg) - (u64)base)) / (u64)base) + 1;
+      }
+      return launch_mixed_keyswitch(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
+    }
+  }
   if (launch_decompose(stream, c2_pow, work, B, P.n, d, P.d_mod, q_below(P, 31)) != hipSuccess) return LOLHIP_ERR_HIP;
   rc = do_crt(P, stream, work, (int64_t)d.L * B, false);                 // all L*B digit polynomials in one launch
   if (rc) return rc;

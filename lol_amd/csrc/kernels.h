@@ -83,6 +83,24 @@ struct MixedLaunch {
   bool fused;
 };
 bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T);
+// fused key switch on the vector interpreter, arithmetic class 2 (mixed_ks.hip): any m with every prime <= 13, n <= 8192
+struct MixedKeySwitchLaunch {
+  hipStream_t stream;
+  const i64* c2;        // [B][n][T] powerful basis
+  const i64* hint;      // [L][2][n][T] CRT basis
+  const i64* addend;    // [2][B][n][T] CRT basis or null
+  i64* out;             // [2][B][n][T]
+  i64 B;
+  int T;
+  i64 n;
+  const Stage* st_crt; int n_crt;   // the plan's forward program (device copy)
+  const uint32_t* consts32;         // class 2's 32-bit Montgomery pool
+  int cpc;
+  const ModCtx* mod;
+  DecompParams dp;
+  uint32_t magic32;     // 32-bit invariant-divisor constant of dp.base
+};
+hipError_t launch_mixed_keyswitch(const MixedKeySwitchLaunch& a);
 hipError_t launch_mixed(const MixedLaunch& a);
 
 // floating-point side (floatpath.hip): y [B][n] complex doubles (re, im interleaved) / doubles, in place

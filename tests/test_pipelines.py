@@ -268,6 +268,41 @@ def test_gpu_keyswitch(gpu, cpuref, pps, qs, base):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,lower,T", [(15, 2 ** 20, 2), (45, 2 ** 29, 3), (48, 2 ** 26, 2), (1728, 2 ** 20, 2), (14400, 2 ** 19, 2),
+                                       (11648, 2 ** 20, 2), (15015, 2 ** 29, 1), (105, 2 ** 30, 2)])
+def test_gpu_keyswitch_fused_mixed_radix(gpu, cpuref, m, lower, T):
+    """The one-pass key switch on the vector interpreter (k_mixed_keyswitch, arithmetic class 2: every modulus below
+    2^30.15) at indices with odd prime powers — incl. the reference's own key-switch benchmark F64*F9*F25
+    (Benchmarks/Default.hs:49-50, m = 14400) and every coefficients-per-thread variant (n = 8 ... 5760): TrivGad and two
+    bases, with and without addends, (-q, 0] representatives of every operand; against the restatement and against
+    the three-launch path.  (105 with a modulus above 2^30.15 stays on the three-launch path: same answers.)"""
+    pps = lm.factor_pps(m)
+    g = lm.good_qs(m, lower)
+    qs = [next(g) for _ in range(T)]
+    P, R = gpu.Plan(pps, qs), Params(pps, qs)
+    rng = np.random.default_rng(m)
+    qv = np.array(qs)
+    for base, B in ((0, 3), (256, 2), (5, 1)):
+        if R.n > 2000 and base == 5:
+            continue                                          # the CPU restatement of 13+ digits at n = 3840 takes minutes
+        Ld = sum(sr.digit_counts(R, base))
+        c2 = R.random(rng, B)
+        c2[0, 0] = qv - 1
+        c2[0, 1] = qv // 2
+        hint = np.stack([np.stack([R.random(rng, 1)[0] for _ in range(2)]) for _ in range(Ld)])
+        add = np.stack([R.random(rng, B) for _ in range(2)])
+        want = sr.keyswitch(cpuref, R, c2, base, hint)
+        wadd = ((want.astype(object) + add) % np.array(qs, dtype=object)).astype(np.int64)
+        assert np.array_equal(P.keySwitch(c2, base, hint), want), (m, base)
+        assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (m, base, "addend")
+        neg = lambda x: np.where(x > 0, x - qv, 0)
+        assert np.array_equal(P.keySwitch(neg(c2), base, neg(hint), addend=neg(add)), wadd), (m, base, "negative")
+        gpu.debug_set("KEYSWITCH_UNFUSED", True)
+        assert np.array_equal(P.keySwitch(c2, base, hint, addend=add), wadd), (m, base, "three launches")
+        gpu.debug_set("KEYSWITCH_UNFUSED", False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("L", range(4, 15))
 def test_gpu_keyswitch_fused_all_sizes(gpu, cpuref, monkeypatch, L):
     """Every n = 2^L the fused single-pass kernel instantiates (moduli < 2^30), TrivGad and two

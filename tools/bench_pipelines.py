@@ -71,7 +71,8 @@ def main():
     # (pps, moduli, batch): config 5's ring; the same at n = 8192; the reference's non-2-power key-switch benchmark
     # F64*F9*F25 with Zq (1008001 ** 1065601) (lol-apps Benchmarks/Default.hs:49)
     for pps5, qs5, B in (([(2, 11)], [1017857, 1032193], 8192), ([(2, 14)], good_qs(2 ** 14, 2 ** 20, 2), 1024),
-                         ([(2, 6), (3, 2), (5, 2)], [1008001, 1065601], 2048)):
+                         ([(2, 6), (3, 2), (5, 2)], [1008001, 1065601], 2048),
+                         ([(2, 6), (3, 2), (5, 2)], [1008001, 1065601], 8192)):      # the same with a digit slab beyond the Infinity Cache
         P = lol_amd.Plan(pps5, qs5)
         for base in (0, 256):
             Ld = P.decomposeLen(base)
@@ -83,6 +84,10 @@ def main():
             slab = B * P.n * P.T * 8
             ms = timeit(lambda: L.lolhip_keyswitch_batch(P._h, st, ptr(c2), base, ptr(hint), 2, ptr(add), ptr(out), ptr(work), B))
             report("keyswitch", f"m={P.m} T=2 q~2^20 base={base} L={Ld} B={B}", ms, B, 5 * slab)
+            L.lolhip_debug_set(b"KEYSWITCH_UNFUSED", 1)
+            ms = timeit(lambda: L.lolhip_keyswitch_batch(P._h, st, ptr(c2), base, ptr(hint), 2, ptr(add), ptr(out), ptr(work), B))
+            L.lolhip_debug_set(b"KEYSWITCH_UNFUSED", 0)
+            report("keyswitch_three_launches", f"m={P.m} T=2 q~2^20 base={base} L={Ld} B={B}", ms, B, 5 * slab)
             ms = timeit(lambda: L.lolhip_decompose_batch(P._h, st, ptr(c2), base, ptr(work), B))
             report("  decompose", f"L={Ld}", ms, B, (1 + Ld) * slab)
             ms = timeit(lambda: L.lolhip_crt_batch(P._h, st, ptr(work), Ld * B))
