@@ -5,9 +5,24 @@
 namespace lolhip {
 
 template <int CLS, int MODE> hipError_t launch_cls(const MixedLaunch& a);     // MODE 0: one program, 2: fused poly-mul
-#define LOLHIP_EXT(C) extern template hipError_t launch_cls<C, 0>(const MixedLaunch&); extern template hipError_t launch_cls<C, 2>(const MixedLaunch&);
+template <int CLS, int MODE, int KMAX> hipError_t launch_cls_k(const MixedLaunch& a);
+#define LOLHIP_EXT(C) extern template hipError_t launch_cls<C, 0>(const MixedLaunch&);
 LOLHIP_EXT(0) LOLHIP_EXT(1) LOLHIP_EXT(2) LOLHIP_EXT(3)
 #undef LOLHIP_EXT
+extern template hipError_t launch_cls<1, 2>(const MixedLaunch&);
+extern template hipError_t launch_cls<2, 2>(const MixedLaunch&);
+// the fused poly-mul of the 64-bit classes: one translation unit per coefficients-per-thread variant
+#define LOLHIP_EXT(C) extern template hipError_t launch_cls_k<C, 2, 12>(const MixedLaunch&); extern template hipError_t launch_cls_k<C, 2, 16>(const MixedLaunch&);
+LOLHIP_EXT(0) LOLHIP_EXT(3)
+#undef LOLHIP_EXT
+// same geometry rule as mixed_impl.h mixed_geom: up to ~2048 packed coefficients per workgroup, 128/256/512 threads
+static bool fused_k12(const MixedLaunch& a) {
+  int ppw = 1;
+  while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
+  const size_t coeffs = (size_t)ppw * a.n;
+  const int threads = coeffs > 4096 ? 512 : (coeffs > 2048 ? 256 : 128);
+  return (coeffs + threads - 1) / threads <= 12;
+}
 
 bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T) {
   if (n > 8192) return false;
@@ -25,9 +40,9 @@ bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T
 hipError_t launch_mixed(const MixedLaunch& a) {
   if (a.B == 0) return hipSuccess;
   switch (a.cls) {
-    case 0: return a.fused ? launch_cls<0, 2>(a) : launch_cls<0, 0>(a);
+    case 0: return a.fused ? (fused_k12(a) ? launch_cls_k<0, 2, 12>(a) : launch_cls_k<0, 2, 16>(a)) : launch_cls<0, 0>(a);
     case 1: return a.fused ? launch_cls<1, 2>(a) : launch_cls<1, 0>(a);
-    case 3: return a.fused ? launch_cls<3, 2>(a) : launch_cls<3, 0>(a);
+    case 3: return a.fused ? (fused_k12(a) ? launch_cls_k<3, 2, 12>(a) : launch_cls_k<3, 2, 16>(a)) : launch_cls<3, 0>(a);
     default: return a.fused ? launch_cls<2, 2>(a) : launch_cls<2, 0>(a);
   }
 

@@ -240,12 +240,18 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
   for (int i = 0; i < D; ++i) v[i] = base[i * rts];
   apply_kind<CLS, D>(st, v, o, cst, mc);
   if (st.tw_off >= 0) {                  // the diagonal folded into this stage (crtTwiddle/dftTwiddle, mhat^-1, oddRad^-1)
-    const int pi = mdiv(x0, n_magic);
-    const int xi0 = x0 - pi * n;
+    if (st.tw_per > 0) {                 // this stage's own diagonal (forward programs): consecutive entries, one division per vector
+      const PT<CLS>* tw = cst + st.tw_off + (blk - mdiv(blk, st.m_twper) * st.tw_per) * D;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
-      o[i] = m_mul<CLS>(o[i], cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod], mc);
+      for (int i = 0; i < D; ++i) o[i] = m_mul<CLS>(o[i], tw[i], mc);
+    } else {
+      const int pi = mdiv(x0, n_magic);
+      const int xi0 = x0 - pi * n;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
+        o[i] = m_mul<CLS>(o[i], cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod], mc);
+      }
     }
   }
 #pragma unroll
@@ -281,8 +287,13 @@ __device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict_
   }
   const PT<CLS>* M = cst + st.mat_off;          // dense kinds only (the dispatcher sends the L and G maps to stage_vec)
   const bool has_tw = st.tw_off >= 0;
+  const bool own_tw = st.tw_per > 0;     // see stage_vec
   int xi0 = 0;
-  if (has_tw) { const int pi = mdiv(x0, n_magic); xi0 = x0 - pi * n; }
+  const PT<CLS>* twp = cst + st.tw_off;
+  if (has_tw) {
+    if (own_tw) twp += (blk - mdiv(blk, st.m_twper) * st.tw_per) * D;
+    else { const int pi = mdiv(x0, n_magic); xi0 = x0 - pi * n; }
+  }
   // row by row, each stored as soon as it is complete (every input is in registers already): 4 d + 4 live values
 #pragma unroll
   for (int i = 0; i < D; ++i) {
@@ -290,8 +301,9 @@ __device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict_
 #pragma unroll
     for (int w = 0; w < W; ++w) o[w] = m_dot<CLS, D>(v[w], M + i * D, mc);
     if (has_tw) {
-      const int xd = mdiv(xi0 + i * rts, st.m_twdiv);
-      const PT<CLS> tw = cst[st.tw_off + xd - mdiv(xd, st.m_twmod) * st.tw_mod];
+      int ti = i;
+      if (!own_tw) { const int xd = mdiv(xi0 + i * rts, st.m_twdiv); ti = xd - mdiv(xd, st.m_twmod) * st.tw_mod; }
+      const PT<CLS> tw = twp[ti];
 #pragma unroll
       for (int w = 0; w < W; ++w) o[w] = m_mul<CLS>(o[w], tw, mc);
     }
@@ -573,26 +585,33 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
   }
 }
 
+// one kernel instantiation per (class, mode, coefficients per thread): the 64-bit fused poly-mul takes minutes to
+// compile per instantiation, so its two KMAX variants live in separate translation units (mixed_cls{0,3}f{12,16}.hip)
+struct MixedGeom { int ppw; i64 ngroups; size_t lds_bytes; int threads; i64 grid; size_t per_thread; };
+template <int CLS> static MixedGeom mixed_geom(const MixedLaunch& a) {
+  MixedGeom g;
+  // pack small polynomials up to ~2048 coefficients per workgroup
+  g.ppw = 1;
+  while ((size_t)(g.ppw * 2) * a.n <= 2048 && g.ppw * 2 <= a.B) g.ppw *= 2;
+  g.ngroups = (a.B + g.ppw - 1) / g.ppw;
+  const size_t coeffs = (size_t)g.ppw * a.n;
+  g.lds_bytes = coeffs * sizeof(MV<CLS>);
+  g.threads = coeffs > 4096 ? 512 : (coeffs > 2048 ? 256 : 128);     // coeffs <= 16 * threads
+  g.grid = g.ngroups * a.T;
+  if (g.grid > 65536) g.grid = 65536;
+  g.per_thread = (coeffs + g.threads - 1) / g.threads;
+  return g;
+}
+template <int CLS, int MODE, int KMAX>
+hipError_t launch_cls_k(const MixedLaunch& a) {
+  const MixedGeom g = mixed_geom<CLS>(a);
+  hipLaunchKernelGGL((k_mixed<CLS, MODE, KMAX>), dim3((unsigned)g.grid), dim3(g.threads), g.lds_bytes, a.stream, a.y, a.a, a.b,
+                     a.B, a.T, (int)a.n, g.ppw, g.ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.consts32, a.cpc, a.mod);
+  return hipGetLastError();
+}
 template <int CLS, int MODE>
 hipError_t launch_cls(const MixedLaunch& a) {
-  using V = MV<CLS>;
-  // pack small polynomials up to ~2048 coefficients per workgroup
-  int ppw = 1;
-  while ((size_t)(ppw * 2) * a.n <= 2048 && ppw * 2 <= a.B) ppw *= 2;
-  const i64 ngroups = (a.B + ppw - 1) / ppw;
-  const size_t coeffs = (size_t)ppw * a.n;
-  const size_t lds_bytes = coeffs * sizeof(V);
-  const int threads = coeffs > 4096 ? 512 : (coeffs > 2048 ? 256 : 128);     // coeffs <= 16 * threads
-  i64 grid = ngroups * a.T;
-  if (grid > 65536) grid = 65536;
-  const size_t per_thread = (coeffs + threads - 1) / threads;
-#define LOLHIP_MIXED_LAUNCH(K)                                                                                         \
-  hipLaunchKernelGGL((k_mixed<CLS, MODE, K>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.y, a.a, a.b, \
-                     a.B, a.T, (int)a.n, ppw, ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.consts32, a.cpc, a.mod)
-  if (per_thread <= 12) LOLHIP_MIXED_LAUNCH(12);
-  else LOLHIP_MIXED_LAUNCH(16);
-#undef LOLHIP_MIXED_LAUNCH
-  return hipGetLastError();
+  return mixed_geom<CLS>(a).per_thread <= 12 ? launch_cls_k<CLS, MODE, 12>(a) : launch_cls_k<CLS, MODE, 16>(a);
 }
 
 }  // namespace lolhip

@@ -283,7 +283,12 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   // ---- generic stage programs + constant pool ---------------------------------
   auto magic40 = [](i64 v) -> uint64_t { return (uint64_t)(((unsigned __int128)1 << 40) / (uint64_t)(v > 0 ? v : 1)) + 1; };
   auto finish = [&](std::vector<Stage>& st) {
-    for (auto& s : st) { s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod); }
+    for (auto& s : st) {
+      s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod);
+      const bool dense = s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV;
+      s.tw_per = (!sw(SW_NO_OWN_DIAG) && dense && s.tw_off >= 0 && s.tw_mod > 1 && s.tw_div == s.rts && s.tw_mod % s.d == 0) ? s.tw_mod / s.d : 0;
+      s.m_twper = magic40(s.tw_per > 0 ? s.tw_per : 1);
+    }
   };
   PoolBuilder pool(T);
   {  // slot 0: the constant 1 (keeps offsets non-negative and gives an identity diagonal)

@@ -48,9 +48,12 @@ struct Stage {
   int32_t tw_mod;   // diagonal index = (x / tw_div) % tw_mod
   int32_t tw_div;
   int32_t mat_off;  // offset of the d x d coefficient matrix (DFTP/CRTP/CRTPINV), row-major
-  int32_t pad[3];
-  // multiply-shift reciprocals (floor(2^40/v)+1) of rts, d, tw_div, tw_mod: x/v = (x*M)>>40 for x < 2^20
-  uint64_t m_rts, m_d, m_twdiv, m_twmod;
+  // tw_per > 0: the diagonal belongs to THIS stage's own vectors (tw_div == rts, d | tw_mod), so element i of the
+  // vector in block blk takes entry (blk mod tw_per) * d + i — one division per vector instead of two per element
+  int32_t tw_per;   // tw_mod / d, or 0
+  int32_t pad[2];
+  // multiply-shift reciprocals (floor(2^40/v)+1) of rts, d, tw_div, tw_mod, tw_per: x/v = (x*M)>>40 for x < 2^20
+  uint64_t m_rts, m_d, m_twdiv, m_twmod, m_twper;
 };
 
 struct StageProgram {
@@ -145,7 +148,7 @@ void plan_free_device(Plan& P);
 // A/B switches of the launch paths (development and tests): read ONCE from the environment
 // (LOLHIP_<NAME>) into atomics; tests flip them through lolhip_debug_set, never through setenv
 // (getenv racing with setenv is undefined behaviour, and plans are used from concurrent threads).
-enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_COUNT };
+enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_COUNT };
 bool sw(Switch which);
 inline bool pow2_no_t1() { return sw(SW_NO_T1); }
 
