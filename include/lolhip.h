@@ -311,6 +311,22 @@ LOLHIP_API int64_t lolhip_tunnelhint_read(const uint8_t *buf, int64_t len, uint3
                                           int64_t *func_off, int64_t *func_len, int64_t *hint_off, int64_t *hint_len,
                                           int cap_hints);
 
+/* Round 3: the remaining writers (same conventions as the readers above; out = NULL queries the size) and the chain
+ * messages of lol-apps/HomomPRF.proto:18-26 (LinearFuncChain, TunnelHintChain, RoundHintChain: `repeated X = 1`).
+ *  r_write / secretkey_write   message R / SecretKey from integer decoding-basis coefficients xs[n] (and the variance v)
+ *  linearrq_write              message LinearRq from xs [C][n][T] (decoding-basis residues of the output ring m)
+ *  tunnelhint_write            message TunnelHint from an encoded LinearRq, nh encoded KSHints and e, r, s, p
+ *  chain_read                  number of elements + byte ranges (offset, length into buf) of up to cap of them
+ *  chain_write                 the chain message of `count` encoded elements */
+LOLHIP_API int64_t lolhip_r_write(uint32_t m, const int64_t *xs, int64_t n, uint8_t *out, int64_t cap);
+LOLHIP_API int64_t lolhip_secretkey_write(uint32_t m, double v, const int64_t *xs, int64_t n, uint8_t *out, int64_t cap);
+LOLHIP_API int64_t lolhip_linearrq_write(uint32_t e, uint32_t r, uint32_t m, const int64_t *qs, int T, int C, const int64_t *xs,
+                                         int64_t n, uint8_t *out, int64_t cap);
+LOLHIP_API int64_t lolhip_tunnelhint_write(const uint8_t *func, int64_t func_len, const uint8_t *const *hints, const int64_t *hint_len,
+                                           int nh, uint32_t e, uint32_t r, uint32_t s, uint64_t p, uint8_t *out, int64_t cap);
+LOLHIP_API int64_t lolhip_chain_read(const uint8_t *buf, int64_t len, int64_t *off, int64_t *elem_len, int cap);
+LOLHIP_API int64_t lolhip_chain_write(const uint8_t *const *elems, const int64_t *elem_len, int count, uint8_t *out, int64_t cap);
+
 /* Measurement aid: device-to-device copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) with
  * 16 bytes per lane — the read-once/write-once ceiling bench.py quotes beside every HBM-bound leg.
  * variant 0: one tile per workgroup; 1: persistent workgroups. */

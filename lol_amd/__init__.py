@@ -11,9 +11,10 @@ calls raise.
 from .tensor import (  # noqa: F401
     LolHipError, NoDeviceError, Plan, Ext, lib, lib_path, device_count, debug_set, good_q, factor_pps,
     rqproduct_read, rqproduct_write, kshint_read, kshint_write, r_read, secretkey_read, kqproduct_read,
-    linearrq_read, tunnelhint_read,
+    linearrq_read, tunnelhint_read, r_write, secretkey_write, linearrq_write, tunnelhint_write, chain_read, chain_write,
 )
 
 __all__ = ["LolHipError", "NoDeviceError", "Plan", "Ext", "lib", "lib_path", "device_count", "debug_set",
            "good_q", "factor_pps", "rqproduct_read", "rqproduct_write", "kshint_read", "kshint_write", "r_read",
-           "secretkey_read", "kqproduct_read", "linearrq_read", "tunnelhint_read"]
+           "secretkey_read", "kqproduct_read", "linearrq_read", "tunnelhint_read", "r_write", "secretkey_write",
+           "linearrq_write", "tunnelhint_write", "chain_read", "chain_write"]

@@ -444,4 +444,117 @@ int64_t lolhip_tunnelhint_read(const uint8_t* buf, int64_t len, uint32_t* e, uin
   return nh;
 }
 
+// ---- round 3: the writers still missing, and the chain messages of lol-apps/HomomPRF.proto --------------------
+
+// message R { required uint32 m = 1; repeated sint64 xs = 2; }: integer coefficients, decoding basis, as they stand.
+int64_t lolhip_r_write(uint32_t m, const int64_t* xs, int64_t n, uint8_t* out, int64_t cap) {
+  if (n < 0 || (n > 0 && !xs)) return LOLHIP_ERR_INVALID;
+  int64_t total = 1 + varint_len(m);
+  for (int64_t j = 0; j < n; ++j) total += 1 + varint_len(zigzag(xs[j]));
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  *o++ = 0x08; put_varint(o, m);
+  for (int64_t j = 0; j < n; ++j) { *o++ = 0x10; put_varint(o, zigzag(xs[j])); }          // xs = 2, unpacked sint64
+  return (int64_t)(o - out);
+}
+
+// message SecretKey { required R sk = 1; required double v = 2; }  (SHE.proto:9)
+int64_t lolhip_secretkey_write(uint32_t m, double v, const int64_t* xs, int64_t n, uint8_t* out, int64_t cap) {
+  const int64_t rl = lolhip_r_write(m, xs, n, nullptr, 0);
+  if (rl < 0) return rl;
+  const int64_t total = 1 + varint_len((uint64_t)rl) + rl + 1 + 8;
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  *o++ = 0x0A; put_varint(o, (uint64_t)rl);
+  o += lolhip_r_write(m, xs, n, o, rl);
+  *o++ = 0x11;                                                                              // v = 2, 64-bit
+  std::memcpy(o, &v, 8); o += 8;
+  return (int64_t)(o - out);
+}
+
+// message LinearRq { required uint32 e = 1; required uint32 r = 2; repeated RqProduct coeffs = 3; }  (Lol.proto:11)
+// xs [C][n][T]: the function's values on the relative decoding basis, decoding-basis residues of the output ring m.
+int64_t lolhip_linearrq_write(uint32_t e, uint32_t r, uint32_t m, const int64_t* qs, int T, int C, const int64_t* xs, int64_t n,
+                              uint8_t* out, int64_t cap) {
+  if (C < 0 || (C > 0 && n > 0 && !xs)) return LOLHIP_ERR_INVALID;
+  std::vector<int64_t> pl((size_t)C);
+  int64_t total = 1 + varint_len(e) + 1 + varint_len(r);
+  for (int c = 0; c < C; ++c) {
+    const int64_t b = lolhip_rqproduct_write(m, qs, T, xs + (int64_t)c * n * T, n, nullptr, 0);
+    if (b < 0) return b;
+    pl[(size_t)c] = b;
+    total += 1 + varint_len((uint64_t)b) + b;
+  }
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  *o++ = 0x08; put_varint(o, e);
+  *o++ = 0x10; put_varint(o, r);
+  for (int c = 0; c < C; ++c) {
+    *o++ = 0x1A; put_varint(o, (uint64_t)pl[(size_t)c]);                                    // coeffs = 3
+    const int64_t w = lolhip_rqproduct_write(m, qs, T, xs + (int64_t)c * n * T, n, o, pl[(size_t)c]);
+    if (w < 0) return w;
+    o += w;
+  }
+  return (int64_t)(o - out);
+}
+
+// message TunnelHint { LinearRq func = 1; repeated KSHint hint = 2; e = 3; r = 4; s = 5; p = 6; }  (SHE.proto:26),
+// assembled from an encoded LinearRq and nh encoded KSHints (lolhip_linearrq_write / lolhip_kshint_write).
+int64_t lolhip_tunnelhint_write(const uint8_t* func, int64_t func_len, const uint8_t* const* hints, const int64_t* hint_len, int nh,
+                                uint32_t e, uint32_t r, uint32_t s, uint64_t p, uint8_t* out, int64_t cap) {
+  if (!func || func_len < 0 || nh < 0 || (nh > 0 && (!hints || !hint_len))) return LOLHIP_ERR_INVALID;
+  int64_t total = 1 + varint_len((uint64_t)func_len) + func_len + 1 + varint_len(e) + 1 + varint_len(r) + 1 + varint_len(s) + 1 + varint_len(p);
+  for (int i = 0; i < nh; ++i) {
+    if (!hints[i] || hint_len[i] < 0) return LOLHIP_ERR_INVALID;
+    total += 1 + varint_len((uint64_t)hint_len[i]) + hint_len[i];
+  }
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  *o++ = 0x0A; put_varint(o, (uint64_t)func_len); std::memcpy(o, func, (size_t)func_len); o += func_len;
+  for (int i = 0; i < nh; ++i) { *o++ = 0x12; put_varint(o, (uint64_t)hint_len[i]); std::memcpy(o, hints[i], (size_t)hint_len[i]); o += hint_len[i]; }
+  *o++ = 0x18; put_varint(o, e);
+  *o++ = 0x20; put_varint(o, r);
+  *o++ = 0x28; put_varint(o, s);
+  *o++ = 0x30; put_varint(o, p);
+  return (int64_t)(o - out);
+}
+
+// lol-apps/HomomPRF.proto:18-26 — LinearFuncChain { repeated LinearRq funcs = 1 }, TunnelHintChain { repeated TunnelHint
+// hints = 1 }, RoundHintChain { repeated KSHint hints = 1 }: one `repeated` sub-message field each.  read: the number of
+// elements and the byte ranges (offset, length into buf) of up to cap of them, for the element readers above.
+int64_t lolhip_chain_read(const uint8_t* buf, int64_t len, int64_t* off, int64_t* elem_len, int cap) {
+  if (!buf || len < 0) return LOLHIP_ERR_INVALID;
+  Reader rd{buf, buf + len};
+  int64_t cnt = 0;
+  while (rd.p < rd.end) {
+    uint64_t key;
+    if (!rd.varint(key)) return LOLHIP_ERR_INVALID;
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 1 && wt == 2) {
+      const uint8_t* b; int64_t l;
+      if (!sub(rd, b, l)) return LOLHIP_ERR_INVALID;
+      if (cnt < cap) { if (off) off[cnt] = b - buf; if (elem_len) elem_len[cnt] = l; }
+      ++cnt;
+    } else if (!rd.skip(wt)) return LOLHIP_ERR_INVALID;
+  }
+  return cnt;
+}
+int64_t lolhip_chain_write(const uint8_t* const* elems, const int64_t* elem_len, int count, uint8_t* out, int64_t cap) {
+  if (count < 0 || (count > 0 && (!elems || !elem_len))) return LOLHIP_ERR_INVALID;
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!elems[i] || elem_len[i] < 0) return LOLHIP_ERR_INVALID;
+    total += 1 + varint_len((uint64_t)elem_len[i]) + elem_len[i];
+  }
+  if (!out) return total;
+  if (cap < total) return LOLHIP_ERR_INVALID;
+  uint8_t* o = out;
+  for (int i = 0; i < count; ++i) { *o++ = 0x0A; put_varint(o, (uint64_t)elem_len[i]); std::memcpy(o, elems[i], (size_t)elem_len[i]); o += elem_len[i]; }
+  return (int64_t)(o - out);
+}
+
 }  // extern "C"

@@ -132,6 +132,15 @@ def lib():
     L.lolhip_linearrq_read.argtypes = [u8p, i64, u32p, u32p, C.POINTER(ci), u32p, _i64p, ci, C.POINTER(ci), _i64p, i64]
     L.lolhip_kshint_write.argtypes = [C.c_uint32, _i64p, ci, ci, ci, _i64p, i64, C.c_uint64, C.c_uint64, u8p, i64]
     L.lolhip_tunnelhint_read.argtypes = [u8p, i64, u32p, u32p, u32p, C.POINTER(C.c_uint64), _i64p, _i64p, _i64p, _i64p, ci]
+    u8pp = C.POINTER(C.POINTER(C.c_uint8))
+    L.lolhip_r_write.argtypes = [C.c_uint32, _i64p, i64, u8p, i64]
+    L.lolhip_secretkey_write.argtypes = [C.c_uint32, C.c_double, _i64p, i64, u8p, i64]
+    L.lolhip_linearrq_write.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _i64p, ci, ci, _i64p, i64, u8p, i64]
+    L.lolhip_tunnelhint_write.argtypes = [u8p, i64, u8pp, _i64p, ci, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u8p, i64]
+    L.lolhip_chain_read.argtypes = [u8p, i64, _i64p, _i64p, ci]
+    L.lolhip_chain_write.argtypes = [u8pp, _i64p, ci, u8p, i64]
+    for nm in ("r_write", "secretkey_write", "linearrq_write", "tunnelhint_write", "chain_read", "chain_write"):
+        getattr(L, f"lolhip_{nm}").restype = i64
     for nm in ("r_read", "secretkey_read", "kqproduct_read", "linearrq_read", "kshint_write", "tunnelhint_read"):
         getattr(L, f"lolhip_{nm}").restype = i64
     L.lolhip_debug_set.argtypes = [C.c_char_p, ci]
@@ -308,6 +317,68 @@ def tunnelhint_read(data: bytes):
     return {"e": int(e.value), "r": int(r.value), "s": int(s.value), "p": int(p.value),
             "func": linearrq_read(data[fo.value: fo.value + fl.value]),
             "hints": [kshint_read(data[int(o): int(o) + int(l)]) for o, l in zip(ho[:nh], hl[:nh])]}
+
+
+def _two_pass(fn, *args) -> bytes:
+    """size query (out = NULL), then the write"""
+    need = fn(*args, None, 0)
+    _check(min(need, 0))
+    buf = (C.c_uint8 * max(need, 1))()
+    wrote = fn(*args, buf, need)
+    _check(min(wrote, 0))
+    return bytes(buf[:wrote])
+
+
+def _byte_parts(parts):
+    """list of bytes objects -> (array of pointers, array of lengths, keep-alive list)"""
+    keep = [(C.c_uint8 * max(len(p), 1)).from_buffer_copy(p if p else b"\0") for p in parts]
+    ptrs = (C.POINTER(C.c_uint8) * max(len(parts), 1))(*[C.cast(k, C.POINTER(C.c_uint8)) for k in keep])
+    lens = np.array([len(p) for p in parts] or [0], dtype=np.int64)
+    return ptrs, lens, keep
+
+
+def r_write(m: int, xs) -> bytes:
+    """integer decoding-basis coefficients xs [n] -> Lol.proto `R` bytes."""
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    return _two_pass(lib().lolhip_r_write, m, xs.ctypes.data_as(_i64p), xs.size)
+
+
+def secretkey_write(m: int, v: float, xs) -> bytes:
+    """SHE.proto `SecretKey` (ring element xs [n] as `R`, scaled variance v)."""
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    return _two_pass(lib().lolhip_secretkey_write, m, C.c_double(v), xs.ctypes.data_as(_i64p), xs.size)
+
+
+def linearrq_write(e: int, r: int, m: int, qs, xs) -> bytes:
+    """xs [C][n][T] (values of an E-linear function on the relative decoding basis) -> Lol.proto `LinearRq` bytes."""
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    Cn, n, T = xs.shape
+    qa = np.ascontiguousarray(qs, dtype=np.int64)
+    return _two_pass(lib().lolhip_linearrq_write, e, r, m, qa.ctypes.data_as(_i64p), T, Cn, xs.ctypes.data_as(_i64p), n)
+
+
+def tunnelhint_write(func: bytes, hints, e: int, r: int, s: int, p: int) -> bytes:
+    """SHE.proto `TunnelHint` from an encoded LinearRq and a list of encoded KSHints."""
+    fbuf = (C.c_uint8 * max(len(func), 1)).from_buffer_copy(func if func else b"\0")
+    ptrs, lens, keep = _byte_parts(list(hints))
+    return _two_pass(lib().lolhip_tunnelhint_write, fbuf, len(func), ptrs, lens.ctypes.data_as(_i64p), len(hints), e, r, s, p)
+
+
+def chain_write(elems) -> bytes:
+    """HomomPRF.proto chain (LinearFuncChain / TunnelHintChain / RoundHintChain) of encoded elements."""
+    ptrs, lens, keep = _byte_parts(list(elems))
+    return _two_pass(lib().lolhip_chain_write, ptrs, lens.ctypes.data_as(_i64p), len(elems))
+
+
+def chain_read(data: bytes):
+    """HomomPRF.proto chain -> list of the encoded elements (hand them to linearrq_read / tunnelhint_read / kshint_read)."""
+    L_ = lib()
+    raw = _raw(data)
+    cnt = L_.lolhip_chain_read(raw, len(data), None, None, 0)
+    _check(min(cnt, 0))
+    off, ln = np.zeros(max(cnt, 1), dtype=np.int64), np.zeros(max(cnt, 1), dtype=np.int64)
+    _check(min(L_.lolhip_chain_read(raw, len(data), off.ctypes.data_as(_i64p), ln.ctypes.data_as(_i64p), cnt), 0))
+    return [data[int(o): int(o) + int(l)] for o, l in zip(off[:cnt], ln[:cnt])]
 
 
 def _np(a):

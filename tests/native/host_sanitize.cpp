@@ -128,6 +128,8 @@ int main() {
     (void)lolhip_kqproduct_read(b, l, &m, q, 8, &Tt, outd.data(), (int64_t)outd.size());
     (void)lolhip_linearrq_read(b, l, &e, &r, &C, &m, q, 8, &Tt, out.data(), (int64_t)out.size());
     (void)lolhip_tunnelhint_read(b, l, &e, &r, &s, &p, &fo, &fl, ho, hl, 4);
+    (void)lolhip_chain_read(b, l, ho, hl, 4);
+    (void)lolhip_chain_read(b, l, nullptr, nullptr, 0);
   };
   {
     uint32_t m; int Tt, Ll, Kk; int64_t q[8];
@@ -136,12 +138,38 @@ int main() {
     CHECK(m == 12 && Tt == T && Ll == L && Kk == K);
     for (size_t i = 0; i < xs.size(); ++i) { int64_t w = xs[i] % qs[i % T]; if (w < 0) w += qs[i % T]; CHECK(back[i] == w); }
   }
-  for (const std::vector<uint8_t>* src : {&rq, &ks}) {
+  // round 3 writers: LinearRq, TunnelHint, a chain of them, R, SecretKey — size query = bytes written, short buffers refused
+  const int64_t len3 = lolhip_linearrq_write(4, 12, 12, qs, T, K, xs.data(), n, nullptr, 0);
+  std::vector<uint8_t> lin((size_t)len3);
+  CHECK(len3 > 0 && lolhip_linearrq_write(4, 12, 12, qs, T, K, xs.data(), n, lin.data(), len3) == len3);
+  CHECK(lolhip_linearrq_write(4, 12, 12, qs, T, K, xs.data(), n, lin.data(), len3 - 1) == LOLHIP_ERR_INVALID);
+  const uint8_t* hp[2] = {ks.data(), ks.data()};
+  const int64_t hl2[2] = {len2, len2};
+  const int64_t len4 = lolhip_tunnelhint_write(lin.data(), len3, hp, hl2, 2, 4, 12, 12, 257, nullptr, 0);
+  std::vector<uint8_t> th((size_t)len4);
+  CHECK(len4 > 0 && lolhip_tunnelhint_write(lin.data(), len3, hp, hl2, 2, 4, 12, 12, 257, th.data(), len4) == len4);
+  {
+    uint32_t e, r, s2; uint64_t p; int64_t fo, fl, ho[4], hl[4];
+    CHECK(lolhip_tunnelhint_read(th.data(), len4, &e, &r, &s2, &p, &fo, &fl, ho, hl, 4) == 2);
+    CHECK(e == 4 && r == 12 && s2 == 12 && p == 257 && fl == len3 && hl[0] == len2 && hl[1] == len2);
+  }
+  const uint8_t* cp[3] = {th.data(), th.data(), th.data()};
+  const int64_t cl[3] = {len4, len4, len4};
+  const int64_t len5 = lolhip_chain_write(cp, cl, 3, nullptr, 0);
+  std::vector<uint8_t> chain((size_t)len5);
+  CHECK(len5 > 0 && lolhip_chain_write(cp, cl, 3, chain.data(), len5) == len5);
+  { int64_t off[4], ln[4]; CHECK(lolhip_chain_read(chain.data(), len5, off, ln, 4) == 3 && ln[2] == len4); }
+  const int64_t rv[5] = {-3, 0, 7, ((int64_t)1 << 50), -((int64_t)1 << 50)};
+  const int64_t len6 = lolhip_secretkey_write(12, 0.5, rv, 5, nullptr, 0);
+  std::vector<uint8_t> skb((size_t)len6);
+  CHECK(len6 > 0 && lolhip_secretkey_write(12, 0.5, rv, 5, skb.data(), len6) == len6);
+  { uint32_t m; double v; int64_t back[5]; CHECK(lolhip_secretkey_read(skb.data(), len6, &m, &v, back, 5) == 5 && m == 12 && v == 0.5 && back[4] == rv[4]); }
+  for (const std::vector<uint8_t>* src : {&rq, &ks, &chain, &skb}) {
     for (int64_t l = 0; l <= (int64_t)src->size(); ++l) {          // every truncation, exact-size heap copy: overreads trap
       std::vector<uint8_t> cut(src->begin(), src->begin() + l);
       read_all(cut.data(), l);
     }
-    for (int it = 0; it < 4000; ++it) {                             // random byte mutations
+    for (int it = 0; it < 2500; ++it) {                             // random byte mutations
       std::vector<uint8_t> mut(*src);
       const int flips = 1 + (int)(rng() % 3);
       for (int f = 0; f < flips; ++f) mut[rng() % mut.size()] = (uint8_t)rng();

@@ -247,3 +247,60 @@ def test_r_secretkey_kq_linearrq_tunnelhint_against_google_protobuf():
     for bad in (raw[:-3], raw[:20], lin.SerializeToString()):         # truncated; a LinearRq is not a TunnelHint
         with pytest.raises(lol_amd.LolHipError):
             lol_amd.tunnelhint_read(bad)
+
+
+def test_remaining_writers_and_homomprf_chains_against_google_protobuf():
+    """Round 3: liblolhip WRITES R, SecretKey, LinearRq and TunnelHint and reads/writes the chain messages of
+    lol-apps/HomomPRF.proto:18-26; google.protobuf parses every byte string back to the same content, and where
+    the encoding is canonical (unpacked sint64, fields in tag order: what hprotoc emits) the bytes are identical."""
+    import lol_amd
+    _messages()
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    rng = np.random.default_rng(11)
+    # R / SecretKey
+    vals = [int(v) for v in rng.integers(-9, 10, size=6)] + [2 ** 40, -2 ** 40]
+    r_bytes = lol_amd.r_write(20, vals)
+    R = _messages.R(); R.ParseFromString(r_bytes)
+    assert R.m == 20 and list(R.xs) == vals and R.SerializeToString() == r_bytes
+    assert lol_amd.r_read(r_bytes)[1].tolist() == vals
+    sk_bytes = lol_amd.secretkey_write(20, 1.75, vals)
+    SK = _messages.SecretKey(); SK.ParseFromString(sk_bytes)
+    assert SK.v == 1.75 and list(SK.sk.xs) == vals and SK.SerializeToString() == sk_bytes
+    assert lol_amd.secretkey_read(sk_bytes)[0:2] == (20, 1.75)
+    # LinearRq
+    ms, qs = 24, [97, lm.first_good_q(24, 2 ** 40)]
+    S = Params(lm.factor_pps(ms), qs)
+    coeffs = np.stack([S.random(rng, 1)[0] for _ in range(4)])
+    lin_bytes = lol_amd.linearrq_write(4, 16, ms, qs, coeffs)
+    lin = _messages.LinearRq(); lin.ParseFromString(lin_bytes)
+    assert (lin.e, lin.r, len(lin.coeffs)) == (4, 16, 4) and lin.SerializeToString() == lin_bytes
+    e, r, m2, qs2, xs = lol_amd.linearrq_read(lin_bytes)
+    assert (e, r, m2, qs2) == (4, 16, ms, qs) and np.array_equal(xs, coeffs)
+    # TunnelHint = LinearRq + two KSHints + e, r, s, p
+    hint_x = [np.stack([np.stack([S.random(rng, 1)[0] for _ in range(2)]) for _ in range(3)]) for _ in range(2)]
+    hint_bytes = [lol_amd.kshint_write(ms, qs, x, gad=(h, h + 1)) for h, x in enumerate(hint_x)]
+    th_bytes = lol_amd.tunnelhint_write(lin_bytes, hint_bytes, 4, 16, 24, 2 ** 40 + 15)
+    th = _messages.TunnelHint(); th.ParseFromString(th_bytes)
+    assert (th.e, th.r, th.s, th.p, len(th.hint)) == (4, 16, 24, 2 ** 40 + 15, 2) and th.SerializeToString() == th_bytes
+    d = lol_amd.tunnelhint_read(th_bytes)
+    assert np.array_equal(d["func"][4], coeffs) and all(np.array_equal(d["hints"][h][2], hint_x[h]) for h in range(2))
+    # the chains of HomomPRF.proto, declared through a dynamic descriptor that imports the messages above by bytes
+    fd = descriptor_pb2.FileDescriptorProto(name="homomprf_test.proto", package="crypto.proto.HomomPRF", syntax="proto2")
+    F = descriptor_pb2.FieldDescriptorProto
+    for nm in ("LinearFuncChain", "TunnelHintChain", "RoundHintChain"):
+        msg = fd.message_type.add(name=nm)
+        msg.field.add(name="elems", number=1, type=F.TYPE_BYTES, label=F.LABEL_REPEATED)      # a sub-message and bytes share wire type 2
+    pool = descriptor_pool.DescriptorPool(); pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    cls = (lambda n: get(pool.FindMessageTypeByName("crypto.proto.HomomPRF." + n))) if get else \
+          (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("crypto.proto.HomomPRF." + n)))
+    for nm, elems in (("LinearFuncChain", [lin_bytes, lin_bytes]), ("TunnelHintChain", [th_bytes, th_bytes, th_bytes]),
+                      ("RoundHintChain", hint_bytes), ("RoundHintChain", [])):
+        chain = lol_amd.chain_write(elems)
+        g = cls(nm)(); g.ParseFromString(chain)
+        assert list(g.elems) == elems and g.SerializeToString() == chain
+        assert lol_amd.chain_read(chain) == elems
+    assert lol_amd.tunnelhint_read(lol_amd.chain_read(lol_amd.chain_write([th_bytes]))[0])["p"] == 2 ** 40 + 15
+    with pytest.raises(lol_amd.LolHipError):
+        lol_amd.chain_read(lol_amd.chain_write([th_bytes])[:-2])          # truncated
