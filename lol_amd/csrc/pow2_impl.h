@@ -500,9 +500,13 @@ __device__ __forceinline__ void tw_fetch(LevelTwT<V>& t, const TwCtxT<V>& tw, in
         // through the CONSTANT address space: a uniform load from it is an s_load whatever else the kernel does.
         // As a plain global load hipcc demotes it to a per-lane vector load as soon as it cannot prove the
         // table unclobbered (seen in pow2_pipe.hip, where it then queued behind the LDS-DMA in vmcnt order)
-        typedef const __attribute__((address_space(4))) V* cptr_t;
-        const cptr_t cp = (cptr_t)(sp + 2 * cidx);
-        t.w[ord] = cp[0]; t.wp[ord] = cp[1];
+        if constexpr (sizeof(V) == 4) {
+          typedef const __attribute__((address_space(4))) V* cptr_t;
+          const cptr_t cp = (cptr_t)(sp + 2 * cidx);
+          t.w[ord] = cp[0]; t.wp[ord] = cp[1];
+        } else {        // the 64-bit classes always got s_load; through the constant space they spill 26 SGPRs instead of 6
+          t.w[ord] = sp[2 * cidx]; t.wp[ord] = sp[2 * cidx + 1];
+        }
       } else if constexpr (A.ntb + R >= TWL_MIN_L && (2 << beta) <= TWL_HI && (1 << beta) >= TWL_LO) {
         const V* lp = tw.lds_tw + 2 * (cidx - TWL_LO + (xt & ((1 << beta) - 1)));
         if constexpr (sizeof(V) == 8) { const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(lp); t.w[ord] = r.x; t.wp[ord] = r.y; }
