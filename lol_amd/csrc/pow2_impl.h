@@ -201,7 +201,11 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     X = x + t;
     Y = x - t + k.q2;
   } else if constexpr (AR == 1) {
+#ifdef LH_ABL_NO_FWD_CSUB
+    const u64 x = X;                                  // timing-only ablation: results are garbage
+#else
     const u64 x = csubn(X, k.nq4);                    // [0,8q) -> [0,4q)
+#endif
     const u64 xn = shoup_acc<WS>(Y, w, wp, k.nq, x);  // x + t, t in [0,4q)
     const u64 z = shl1_add64u(x, k.q4);                // 2x + 4q
     X = xn;

@@ -171,6 +171,13 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
   // carry with s_nop; inside a block there is nothing to pad: VGPR RAW is interlocked).
   u64 Q, t, h;
   u32 ah, bh;
+#if defined(LH_ABL_PADN) && LH_ABL_PADN == 1      // timing-only ablations: what an s_nop costs in this kernel
+#define LH_ABL_PAD "\n\ts_nop 0"
+#elif defined(LH_ABL_PADN) && LH_ABL_PADN == 2
+#define LH_ABL_PAD "\n\ts_nop 1"
+#else
+#define LH_ABL_PAD ""
+#endif
 #define LH_SHOUP_BLOCKS(WC)                                                                          \
   asm("v_mul_hi_u32 %1, %3, %5\n\t"                                                                  \
       "v_mul_hi_u32 %2, %4, %6\n\t"                                                                  \
@@ -185,7 +192,7 @@ LH_D u64 shoup_acc(u64 y, u64 w, u64 wp, u64 nq, u64 init) {
       "v_mad_u64_u32 %0, vcc, %6, %8, %0\n\t"                                                        \
       "v_mad_u64_u32 %1, vcc, %3, %4, %1\n\t"                                                        \
       "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\t"                                                        \
-      "v_mad_u64_u32 %1, vcc, %7, %8, %1"                                                            \
+      "v_mad_u64_u32 %1, vcc, %7, %8, %1" LH_ABL_PAD                                                 \
       : "=&v"(t), "=&v"(h)                                                                           \
       : WC(lo32(w)), WC(hi32(w)), "v"(lo32(y)), "v"(hi32(y)), "v"(lo32(Q)), "v"(hi32(Q)),            \
         "s"(lo32(nq)), "s"(hi32(nq)), "v"(init)      /* nq: wave-uniform, one SGPR operand per mad */ \
