@@ -110,7 +110,10 @@ LOLHIP_API int lolhip_plan_has_crt(const lolhip_plan *p);
 /* Host tables exactly as lol-cpp's shim would marshal them.  Each copies min(len,
  * available) int64 values and returns the available count.
  *   which: 0 ru[k] (CPP.hs:422-432)   1 ruInv[k] (CPP.hs:434-442)   2 mhatInv
- *          3 gCRT  4 gInvCRT (CPP.hs:444-454; [n*T] AoS)            5 qs      */
+ *          3 gCRT  4 gInvCRT (CPP.hs:444-454; [n*T] AoS)            5 qs
+ *          10 / 11 (inspection, tests): the stage program a lone crt / crtInv of an index that is not a power
+ *          of two launches, four values per stage: kind, prime (first level for the 2-power tiles), vector
+ *          length (levels for the tiles), stride                                  */
 LOLHIP_API int64_t lolhip_plan_table(const lolhip_plan *p, int which, int k, int64_t *out, int64_t len);
 
 /* smallest prime > lower congruent to 1 mod m (head of goodQs, ZqBasic.hs:71-73) */
@@ -333,7 +336,7 @@ LOLHIP_API int64_t lolhip_chain_write(const uint8_t *const *elems, const int64_t
 LOLHIP_API int lolhip_copy_slab(void *stream, void *dst, const void *src, int64_t bytes, int variant);
 
 /* Test and A/B aid, not part of the drop-in surface: force a launch path.  `name` is one of
- * GENERIC_SCALAR, NO_FUSED2, NO_POW2_PART, POLYMUL_UNFUSED, KEYSWITCH_UNFUSED, NO_T1, NO_PIPE, FORCE_PIPE, NO_OWN_DIAG (read when a plan is built) (each is
+ * GENERIC_SCALAR, NO_FUSED2, NO_POW2_PART, POLYMUL_UNFUSED, KEYSWITCH_UNFUSED, NO_T1, NO_PIPE, FORCE_PIPE, NO_OWN_DIAG and NO_MERGE (both read when a plan is built) (each is
  * also read ONCE at first use from the environment variable LOLHIP_<name>); value 0 restores the
  * default path.  Every path computes the same residues.  Returns LOLHIP_OK or LOLHIP_ERR_INVALID. */
 LOLHIP_API int lolhip_debug_set(const char *name, int value);

@@ -25,7 +25,7 @@ using namespace lolhip;
 namespace lolhip {
 namespace {
 const char* const kSwitchNames[SW_COUNT] = {"GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED",
-                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG"};
+                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE"};
 std::atomic<int> g_switch[SW_COUNT];
 std::once_flag g_switch_once;
 void switches_init() {
@@ -106,6 +106,22 @@ bool use_mixed(const Plan& P, const StageProgram& sp) {
   return !sw(SW_GENERIC_SCALAR) && mixed_ok(P.n, sp.stages.data(), (int)sp.stages.size(), P.qs.data(), P.T);
 }
 
+// the Z_q CRT programs the vector interpreter runs: the merged prime-power form where the plan has one (class 2)
+// big_ok: the caller launches kernels that take 18-/20-element vectors (lone transforms, the fused poly-mul)
+const StageProgram& zq_crt(const Plan& P, bool big_ok = true) {
+  if (sw(SW_GENERIC_SCALAR)) return P.prog_crt;
+  if (big_ok && !P.prog_crt_mg_big.stages.empty()) return P.prog_crt_mg_big;
+  return !P.prog_crt_mg.stages.empty() ? P.prog_crt_mg : P.prog_crt;
+}
+const StageProgram& zq_crtinv(const Plan& P, bool big_ok = true) {
+  if (sw(SW_GENERIC_SCALAR)) return P.prog_crtinv;
+  if (big_ok && !P.prog_crtinv_mg_big.stages.empty()) return P.prog_crtinv_mg_big;
+  return !P.prog_crtinv_mg.stages.empty() ? P.prog_crtinv_mg : P.prog_crtinv;
+}
+// the one-launch programs of m = 2^e * odd (valid when use_fused2)
+const StageProgram& fused_crt(const Plan& P, bool big_ok = true) { return (big_ok && !P.prog_crt_fused_big.stages.empty()) ? P.prog_crt_fused_big : P.prog_crt_fused; }
+const StageProgram& fused_crtinv(const Plan& P, bool big_ok = true) { return (big_ok && !P.prog_crtinv_fused_big.stages.empty()) ? P.prog_crtinv_fused_big : P.prog_crtinv_fused; }
+
 bool q_below(const Plan& P, int bits) {
   for (u64 q : P.qs) if (q >> bits) return false;
   return true;
@@ -122,7 +138,7 @@ int run_prog(const Plan& P, const StageProgram& sp, hipStream_t s, int64_t* y, i
     MixedLaunch m;
     m.stream = s; m.y = y; m.a = src ? src : y; m.b = nullptr; m.B = B; m.T = P.T; m.n = P.n;
     m.st_a = sp.d_stages; m.n_a = sp.nstages; m.st_b = nullptr; m.n_b = 0;
-    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = false;
+    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = false; m.big = sp.big;
     return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
   GenericLaunch a;
@@ -168,7 +184,7 @@ int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
   // e >= 5, where the m = 2^k kernels' cheaper butterflies outweigh the second pass over the slab
   // (measured at 58 bits: m = 11648 0.62 vs 0.55 ms, m = 14336 0.65 vs 0.52 ms; at 26 bits fused wins everywhere)
   const bool wide = P.mixed_cls == 0 || P.mixed_cls == 3;
-  if (use_fused2(P) && !(wide && P.pow2_part)) return run_prog(P, inverse ? P.prog_crtinv_fused : P.prog_crt_fused, s, y, B);
+  if (use_fused2(P) && !(wide && P.pow2_part)) return run_prog(P, inverse ? fused_crtinv(P) : fused_crt(P), s, y, B);
   if (P.pow2_part && !sw(SW_NO_POW2_PART)) {
     const int64_t blocks = B * (P.n >> P.pow2.L);       // contiguous 2^(e-1)-coefficient blocks
     if (!inverse) {
@@ -178,7 +194,7 @@ int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
     int rc = run_prog(P, P.prog_crtinv_odd, s, y, B);
     return rc ? rc : run_pow2(P, 1, s, y, nullptr, nullptr, blocks);
   }
-  return run_prog(P, inverse ? P.prog_crtinv : P.prog_crt, s, y, B);
+  return run_prog(P, inverse ? zq_crtinv(P) : zq_crt(P), s, y, B);
 }
 
 int divg_ok(const Plan& P) {
@@ -236,6 +252,13 @@ int64_t lolhip_plan_table(const lolhip_plan* p, int which, int k, int64_t* out, 
     case 3: src = &P.gcrt; break;
     case 4: if (P.has_ginvcrt) src = &P.ginvcrt; break;
     case 5: for (u64 q : P.qs) tmp.push_back((i64)q); src = &tmp; break;
+    case 10: case 11: {      // the stage program a lone crt (10) / crtInv (11) launches, four values per stage
+      const bool inv = which == 11;
+      const StageProgram& sp = (P.fused2 && !sw(SW_NO_FUSED2)) ? (inv ? fused_crtinv(P) : fused_crt(P)) : (inv ? zq_crtinv(P) : zq_crt(P));
+      for (const Stage& st : sp.stages) { tmp.push_back(st.kind); tmp.push_back(st.p); tmp.push_back(st.d); tmp.push_back(st.rts); }
+      src = &tmp;
+      break;
+    }
     default: break;
   }
   if (!src) return 0;
@@ -280,15 +303,15 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   const bool unfused = sw(SW_POLYMUL_UNFUSED);                                      // A/B switch
   const bool fused2 = use_fused2(P);
   const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);   // the 2-power factor has its own kernels
-  if (!unfused && !split2 && (fused2 || (use_mixed(P, P.prog_crt) && use_mixed(P, P.prog_crtinv)))) {
+  if (!unfused && !split2 && (fused2 || (use_mixed(P, zq_crt(P)) && use_mixed(P, zq_crtinv(P))))) {
     // one launch: a-hat in registers, b through the same LDS buffer, 3 slab passes (mixed.hip)
-    const StageProgram& pf = fused2 ? P.prog_crt_fused : P.prog_crt;
-    const StageProgram& pi = fused2 ? P.prog_crtinv_fused : P.prog_crtinv;
+    const StageProgram& pf = fused2 ? fused_crt(P) : zq_crt(P);
+    const StageProgram& pi = fused2 ? fused_crtinv(P) : zq_crtinv(P);
     MixedLaunch m;
     m.stream = s; m.y = c; m.a = a; m.b = b; m.B = B; m.T = P.T; m.n = P.n;
     m.st_a = pf.d_stages; m.n_a = pf.nstages;
     m.st_b = pi.d_stages; m.n_b = pi.nstages;
-    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true;
+    m.consts = P.d_consts_mont ? P.d_consts_mont : P.d_consts; m.consts32 = P.d_consts32; m.cpc = P.consts_per_comp; m.mod = P.d_mod; m.cls = P.mixed_cls; m.fused = true; m.big = pf.big || pi.big;
     return launch_mixed(m) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
   // otherwise: crt(a) -> c, crt(b) -> temp, multiply, crtInv.  c may alias a or b.  The temp is a
@@ -301,8 +324,8 @@ int lolhip_polymul_batch(const lolhip_plan* p, void* stream, int64_t* c, const i
   rc = LOLHIP_OK;
   if (!P.pow2_part || sw(SW_NO_POW2_PART)) {
     // stage program alone: transform b into the temp first (c may alias b), then a into c
-    rc = run_prog(P, P.prog_crt, s, tmp, B, b);
-    if (!rc) rc = run_prog(P, P.prog_crt, s, c, B, c != a ? a : nullptr);
+    rc = run_prog(P, zq_crt(P), s, tmp, B, b);
+    if (!rc) rc = run_prog(P, zq_crt(P), s, c, B, c != a ? a : nullptr);
   } else {
     if (hipMemcpyAsync(tmp, b, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
     if (!rc && c != a && hipMemcpyAsync(c, a, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = LOLHIP_ERR_HIP;
@@ -496,8 +519,8 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !sw(SW_KEYSWITCH_UNFUSED)) {
     const bool fused2 = use_fused2(P);
     const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);
-    const StageProgram& pf = fused2 ? P.prog_crt_fused : P.prog_crt;
-    if (!split2 && (fused2 || use_mixed(P, P.prog_crt))) {
+    const StageProgram& pf = fused2 ? fused_crt(P, false) : zq_crt(P, false);      // the key-switch kernel holds two accumulator sets: no 20-element vectors
+    if (!split2 && (fused2 || use_mixed(P, pf))) {
       MixedKeySwitchLaunch l;
       l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B; l.T = P.T; l.n = P.n;
       l.st_crt = pf.d_stages; l.n_crt = pf.nstages; l.consts32 = P.d_consts32; l.cpc = P.consts_per_comp; l.mod = P.d_mod; l.dp = d;

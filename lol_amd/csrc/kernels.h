@@ -74,6 +74,7 @@ struct MixedLaunch {
   i64 n;
   const Stage* st_a; int n_a;     // the program, or crt for the fused poly-mul
   const Stage* st_b; int n_b;     // crtInv for the fused poly-mul
+  bool big = false;               // a program holds 18- or 20-element vectors (merged prime powers, class 2): the BIG kernels
   const u64* consts;              // the pool (classes 2 and 3: the Montgomery copy)
   const uint32_t* consts32;       // its 32-bit copy (classes 1 and 2), else null
   int cpc;

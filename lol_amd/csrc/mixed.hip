@@ -5,14 +5,14 @@
 namespace lolhip {
 
 template <int CLS, int MODE> hipError_t launch_cls(const MixedLaunch& a);     // MODE 0: one program, 2: fused poly-mul
-template <int CLS, int MODE, int KMAX> hipError_t launch_cls_k(const MixedLaunch& a);
+template <int CLS, int MODE, int KMAX, bool BIG = false> hipError_t launch_cls_k(const MixedLaunch& a);
 #define LOLHIP_EXT(C) extern template hipError_t launch_cls<C, 0>(const MixedLaunch&);
 LOLHIP_EXT(0) LOLHIP_EXT(1) LOLHIP_EXT(2) LOLHIP_EXT(3)
 #undef LOLHIP_EXT
 extern template hipError_t launch_cls<1, 2>(const MixedLaunch&);
 extern template hipError_t launch_cls<2, 2>(const MixedLaunch&);
 // the fused poly-mul of the 64-bit classes: one translation unit per coefficients-per-thread variant
-#define LOLHIP_EXT(C) extern template hipError_t launch_cls_k<C, 2, 12>(const MixedLaunch&); extern template hipError_t launch_cls_k<C, 2, 16>(const MixedLaunch&);
+#define LOLHIP_EXT(C) extern template hipError_t launch_cls_k<C, 2, 12, false>(const MixedLaunch&); extern template hipError_t launch_cls_k<C, 2, 16, false>(const MixedLaunch&);
 LOLHIP_EXT(0) LOLHIP_EXT(3)
 #undef LOLHIP_EXT
 // same geometry rule as mixed_impl.h mixed_geom: up to ~2048 packed coefficients per workgroup, 128/256/512 threads
@@ -30,9 +30,9 @@ bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T
   for (int s = 0; s < nstages; ++s) {
     const Stage& st = host_stages[s];
     if (st.kind == ST_DIAG || st.kind == ST_SCALE) continue;
-    if (st.kind == ST_POW2F || st.kind == ST_POW2I) { if (st.d < 1 || st.d > 4) return false; continue; }
+    if (st.kind == ST_POW2F || st.kind == ST_POW2I) { if (st.d < 1 || st.d > 5) return false; continue; }     // 5 levels, 18- and 20-vectors: class 2 plans only (plan.cpp)
     const int d = st.d;
-    if (!(d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 10 || d == 11 || d == 12 || d == 13)) return false;
+    if (!(d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 10 || d == 11 || d == 12 || d == 13 || d == 18 || d == 20)) return false;
   }
   return true;
 }

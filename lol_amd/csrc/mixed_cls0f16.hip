@@ -2,5 +2,5 @@
 // one instantiation of the 64-bit fused kernel takes over two minutes to compile)
 #include "mixed_impl.h"
 namespace lolhip {
-template hipError_t launch_cls_k<0, 2, 16>(const MixedLaunch&);
+template hipError_t launch_cls_k<0, 2, 16, false>(const MixedLaunch&);
 }  // namespace lolhip

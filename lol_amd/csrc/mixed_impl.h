@@ -127,8 +127,8 @@ template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(M
 // one output of a dense stage: sum_c v[c] * row[c] mod q
 template <int CLS, int D>
 __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const PT<CLS>* __restrict__ row, const ModCtx& mc) {
-  static_assert(D <= 16, "16 products below 2^124 fit in 128 bits");
-  if constexpr (CLS == 2) {
+  static_assert(D <= 16 || CLS == 2, "16 products below 2^124 fit in 128 bits");
+  if constexpr (CLS == 2) {      // D <= 13, or the merged prime powers (D = 18, 20) of plans whose moduli leave the room (plan.cpp)
     u64 acc = 0;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc += (u64)v[c] * (u32)row[c];      // one v_mad_u64_u32 per term; D (q-1)^2 < 2^64
@@ -258,6 +258,29 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
   for (int i = 0; i < D; ++i) base[i * rts] = o[i];
 }
 
+// a merged prime power (plan.cpp merge_prime_powers: D = 18, 20; no diagonal): every output is stored as soon as
+// its dot product is reduced — the D inputs are in registers by then — so D + 3 values are live, not 2 D
+template <int CLS, int D>
+__device__ __forceinline__ void stage_vec_big(const Stage& st, MV<CLS>* __restrict__ buf, int vec,
+                                              const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
+  using V = MV<CLS>;
+  const int rts = st.rts;
+  const int blk = mdiv(vec, st.m_rts), r = vec - blk * rts;
+  V* base = buf + (blk * D * rts + r);
+  V v[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = base[i * rts];
+  // (opaque per vector: hoisted out of the loop over vectors, the D x D matrix would be 400 SGPRs spilled to VGPR lanes)
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  const PT<CLS>* M = cst + __builtin_amdgcn_readfirstlane(st.mat_off + z);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    base[i * rts] = m_dot<CLS, D>(v, M + i * D, mc);
+    if (i & 1) __builtin_amdgcn_sched_barrier(0);       // two rows (40 SGPRs) in flight, not the whole matrix
+  }
+}
+
 // FOUR adjacent d-vectors (positions r .. r+3 of one block) per thread, for stages whose stride is a
 // multiple of 4: the four share the index arithmetic, the matrix rows in SGPRs and — because the
 // diagonal's index is x / tw_div with tw_div a multiple of 4 (or the diagonal is a single constant) —
@@ -324,14 +347,18 @@ __device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict_
 // odd primes' stages in any order.  (Unreduced butterflies for q < 2^27 — 7 instead of 12 instructions — were
 // built and measured twice: as a second path in this function they spill 66-99 VGPRs to scratch (crt of 64*9*25
 // 0.18 -> 0.31 ms); as separate instantiations they gain 0-5 % (2^11*7 crt 0.284 -> 0.269 ms) for +50 % build time.)
-template <int CLS, int K, bool INV>
+// FIRST: the tile that starts at level 1 (rts = 1: contiguous, and the table index of every butterfly is a
+// compile-time constant, the same for every tile) — its twiddles are scalar loads into SGPR operands instead of
+// 2^K - 1 per-lane loads with their address arithmetic, which is what lets a 5-level tile (32 residues) fit the
+// 80-VGPR budget of the 32-bit single-program kernels.
+template <int CLS, int K, bool INV, bool FIRST = false>
 __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict__ buf, int tile,
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   constexpr int NE = 1 << K;
   const u64 q = mc.q;
-  const int rts = st.rts, sh = st.p - 1;
-  const int low = tile & (rts - 1), high = tile >> sh;
+  const int rts = FIRST ? 1 : st.rts, sh = FIRST ? 0 : st.p - 1;
+  const int low = FIRST ? 0 : (tile & (rts - 1)), high = tile >> sh;
   V* base = buf + ((high << (sh + K)) | low);
   V v[NE];
   if (rts == 1) {                      // contiguous tile: 16-byte LDS accesses
@@ -410,14 +437,35 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
 // the stage's constants (a whole d x d matrix: 169 SGPRs at p = 13) in registers across the loop: good
 // where there are VGPRs to spill SGPRs into (the fused poly-mul at 128: -3..6 %), bad at the 64-80 of the
 // single-program kernels (scratch spills: crt of m = 15015 0.042 -> 0.058 ms).
-template <int CLS, bool HOIST>
+// BIG (class 2): the 18- and 20-element vectors of merged prime powers (stage_vec_big) are instantiated too.  Separate
+// kernels — inside the ordinary ones these bodies cost every program registers (spills in the fused poly-mul).
+template <int CLS, bool HOIST, bool BIG = false>
 __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, int n, u64 n_magic,
                                            const Stage* __restrict__ stages, int nstages,
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
 #define LOLHIP_LOOP(COUNT, CALL) for (int it = threadIdx.x; it < (COUNT); it += blockDim.x) { CALL; }
 #define LOLHIP_TILES(X) X(2, 1, false) X(3, 1, true) X(4, 2, false) X(5, 2, true) X(6, 3, false) X(7, 3, true) X(8, 4, false) X(9, 4, true)
+#ifndef LH_TILES_FIRST
+#define LH_TILES_FIRST 0      // A/B: the scalar-twiddle form of the tile that starts at level 1
+#endif
+#if !LH_TILES_FIRST
+#define LH_FIRST_SEL 0
+#define LOLHIP_TILES1(X)
+#else
+#define LH_FIRST_SEL 1
+#define LOLHIP_TILES1(X) X(18, 1, false) X(19, 1, true) X(20, 2, false) X(21, 2, true) X(22, 3, false) X(23, 3, true) X(24, 4, false) X(25, 4, true)
+#endif
+#define LOLHIP_TILES5(X)
 #define LOLHIP_VECS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(10) X(11) X(12) X(13)
+#ifdef LH_NO_VL
+#define LOLHIP_VECSL(X)
+#else
+#define LOLHIP_VECSL(X) X(18) X(20)                           // class 2 only: merged prime powers 3^3, 5^2
+#endif
   for (int s = 0; s < nstages; ++s) {
+#ifdef LH_ABL_SKIP_STAGES        // timing-only ablation: bit s set = stage s of every program is skipped (results garbage)
+    if ((LH_ABL_SKIP_STAGES >> s) & 1) continue;
+#endif
     const Stage st = stages[s];
     if (st.kind == ST_DIAG || st.kind == ST_SCALE) {
       for (int x = threadIdx.x; x < tot; x += blockDim.x) {
@@ -427,14 +475,21 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       }
     } else if (st.kind == ST_POW2F || st.kind == ST_POW2I) {
       const int ntile = tot >> st.d;
-      const int sel = st.d * 2 + (st.kind == ST_POW2I ? 1 : 0);
+      // + 16: the tile that starts at level 1 (scalar twiddles; the only one that may hold 5 levels, class 2)
+      const int sel = st.d * 2 + (st.kind == ST_POW2I ? 1 : 0) + (LH_FIRST_SEL && st.rts == 1 ? 16 : 0);
       if constexpr (HOIST) {
 #define LOLHIP_X(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV>(st, buf, it, cst, mc))) break;
-        switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; }
+#define LOLHIP_X1(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc))) break;
+        if constexpr (CLS == 2) { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; } }
+        else { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; } }
+#undef LOLHIP_X1
 #undef LOLHIP_X
       } else {
 #define LOLHIP_X(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV>(st, buf, it, cst, mc); break;
-        LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; })
+#define LOLHIP_X1(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc); break;
+        if constexpr (CLS == 2) { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; }) }
+        else { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; }) }
+#undef LOLHIP_X1
 #undef LOLHIP_X
       }
     } else {
@@ -466,11 +521,17 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       if (!done) {
         if constexpr (HOIST) {
 #define LOLHIP_X(D) case D: LOLHIP_LOOP(nvec, (stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
-          switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }      // other lengths are excluded on the host (mixed_ok)
+#define LOLHIP_XL(D) case D: LOLHIP_LOOP(nvec, (stage_vec_big<CLS, D>(st, buf, it, cst, mc))) break;
+          if constexpr (CLS == 2 && BIG) { switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; } }
+          else { switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; } }      // other lengths are excluded on the host (mixed_ok)
+#undef LOLHIP_XL
 #undef LOLHIP_X
         } else {
 #define LOLHIP_X(D) case D: stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
-          LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; })
+#define LOLHIP_XL(D) case D: stage_vec_big<CLS, D>(st, buf, it, cst, mc); break;
+          if constexpr (CLS == 2 && BIG) { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; }) }
+          else { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }) }
+#undef LOLHIP_XL
 #undef LOLHIP_X
         }
       }
@@ -479,7 +540,10 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
   }
 #undef LOLHIP_LOOP
 #undef LOLHIP_TILES
+#undef LOLHIP_TILES1
+#undef LOLHIP_TILES5
 #undef LOLHIP_VECS
+#undef LOLHIP_VECSL
 }
 
 template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
@@ -495,7 +559,7 @@ template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
 // per CU; the single-program form of the 32-bit classes fits 80 VGPRs (6 waves/SIMD); the fused
 // poly-mul keeps a-hat and b's loads live and gets 128 (4 waves/SIMD), as does the 64-bit class
 // (at 80 it spills: measured slower).
-template <int CLS, int MODE, int KMAX>
+template <int CLS, int MODE, int KMAX, bool BIG = false>
 __global__ void __launch_bounds__(512, (MODE == 0 && CLS == 2) ? LOLHIP_MIXED_W2 : (MODE == 0 && CLS == 1) ? 6 : 4)
 k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int ppw, i64 ngroups,
         const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
@@ -503,7 +567,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
   using V = MV<CLS>;
   // hoisted dispatch (run_stages): the fused poly-mul of the 32-bit classes only — in the 64-bit classes it measured
   // no gain (m = 15015, 61 bits: 0.324 vs 0.320 ms)
-  constexpr bool HOISTED = (MODE == 2 && !wide<CLS>()) || LOLHIP_MIXED_HOIST0;
+  constexpr bool HOISTED = ((MODE == 2 && !wide<CLS>()) || LOLHIP_MIXED_HOIST0) && !BIG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V* buf = reinterpret_cast<V*>(smem);
   const u64 n_magic = (((u64)1 << 40) / (u64)n) + 1;
@@ -550,16 +614,18 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
     if constexpr (MODE == 0) {
       to_lds(ra);
       __syncthreads();
-      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, HOISTED, BIG>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       store16();
     } else {
       const bool square = (a_in == b_in);
       to_lds(ra);
       // b's loads go out now and land under a's stages (holding them back to fit a third
       // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
-      if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
+      // (BIG: b's 2 KMAX raw registers would spill under the 20-element vectors: loaded after a's stages instead)
+      if constexpr (!BIG) if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       __syncthreads();
-      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      run_stages<CLS, HOISTED, BIG>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+      if constexpr (BIG) if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       V ah[KMAX];                        // a-hat: every thread keeps the positions it owns
       {
         const int x0 = fresh(tid);
@@ -570,7 +636,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         __syncthreads();                 // every a-hat coefficient is in registers before b overwrites the buffer
         to_lds(ra);
         __syncthreads();
-        run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
+        run_stages<CLS, HOISTED, BIG>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
       }
       {
         const int x0 = fresh(tid);
@@ -578,7 +644,7 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
         for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (x < tot) buf[x] = m_mul<CLS, false>(ah[k], (u64)buf[x], mc); }
       }
       __syncthreads();
-      run_stages<CLS, HOISTED>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
+      run_stages<CLS, HOISTED, BIG>(buf, tot, n, n_magic, st_b, n_b, cst, mc);
       store16();
     }
     __syncthreads();                     // the buffer is reused by the next item
@@ -602,16 +668,18 @@ template <int CLS> static MixedGeom mixed_geom(const MixedLaunch& a) {
   g.per_thread = (coeffs + g.threads - 1) / g.threads;
   return g;
 }
-template <int CLS, int MODE, int KMAX>
+template <int CLS, int MODE, int KMAX, bool BIG = false>
 hipError_t launch_cls_k(const MixedLaunch& a) {
   const MixedGeom g = mixed_geom<CLS>(a);
-  hipLaunchKernelGGL((k_mixed<CLS, MODE, KMAX>), dim3((unsigned)g.grid), dim3(g.threads), g.lds_bytes, a.stream, a.y, a.a, a.b,
+  hipLaunchKernelGGL((k_mixed<CLS, MODE, KMAX, BIG>), dim3((unsigned)g.grid), dim3(g.threads), g.lds_bytes, a.stream, a.y, a.a, a.b,
                      a.B, a.T, (int)a.n, g.ppw, g.ngroups, a.st_a, a.n_a, a.st_b, a.n_b, a.consts, a.consts32, a.cpc, a.mod);
   return hipGetLastError();
 }
 template <int CLS, int MODE>
 hipError_t launch_cls(const MixedLaunch& a) {
-  return mixed_geom<CLS>(a).per_thread <= 12 ? launch_cls_k<CLS, MODE, 12>(a) : launch_cls_k<CLS, MODE, 16>(a);
+  const bool k12 = mixed_geom<CLS>(a).per_thread <= 12;
+  if constexpr (CLS == 2) if (a.big) return k12 ? launch_cls_k<CLS, MODE, 12, true>(a) : launch_cls_k<CLS, MODE, 16, true>(a);
+  return k12 ? launch_cls_k<CLS, MODE, 12>(a) : launch_cls_k<CLS, MODE, 16>(a);
 }
 
 }  // namespace lolhip

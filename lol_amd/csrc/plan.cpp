@@ -194,6 +194,81 @@ static void build_crt_programs(const std::vector<PP>& pps, const Ring& R, PoolBu
   crtinv->diag(mh_off, 1, 1);
 }
 
+
+// ---- prime powers with a small totient as ONE dense stage (class 2 of the vector interpreter) ------------
+// CRT_{p^e} runs as CRT_p, the crtTwiddle diagonal and e-1 radix-p DFT stages with their diagonals between
+// (crt.cpp:459-538): e round trips through LDS whose fixed cost (index arithmetic, a barrier, one Montgomery
+// reduction per coefficient and stage) exceeds the arithmetic for 3^2, 5^2, 3^3.  Their product is a
+// phi(p^e) x phi(p^e) matrix over Z_q — the same linear map, so the same residues bit for bit — and
+// phi <= 20 fits one register vector: 20 multiply-adds and ONE reduction per coefficient instead of
+// (4 + 5) multiply-adds, two diagonal products and three reductions.  Built by pushing the unit vectors
+// through the staged form on the host; the merged stage replaces the run in a COPY of the program
+// (the floating-point path and the scalar interpreter keep the staged list).
+static bool merge_prime_powers(std::vector<Stage>& st, PoolBuilder& pool, const std::vector<u64>& qs, int max_phi) {
+  bool any = false;
+  std::vector<Stage> out;
+  for (size_t a = 0; a < st.size();) {
+    auto dense = [](const Stage& s) { return s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV; };
+    size_t b = a;
+    if (dense(st[a]) && st[a].p > 2) { b = a + 1; while (b < st.size() && dense(st[b]) && st[b].p == st[a].p) ++b; }
+    if (b < a + 2) { out.push_back(st[a]); ++a; continue; }
+    // the run [a, b) is one prime power: (I (x) A (x) I_R) with R the smallest stride in it
+    i64 R = st[a].rts; int e1 = 0; bool inv = false;
+    for (size_t k = a; k < b; ++k) { R = std::min<i64>(R, st[k].rts); if (st[k].kind == ST_DFTP) ++e1; else if (st[k].kind == ST_CRTPINV) inv = true; }
+    const int p = st[a].p;
+    const i64 phi = (i64)(p - 1) * ipow(p, e1);
+    bool ok = phi <= max_phi && (size_t)(e1 + 1) == b - a;
+    for (size_t k = a; k < b && ok; ++k) {
+      const Stage& s = st[k];
+      if (s.rts % R || phi % ((i64)s.d * (s.rts / R))) ok = false;
+      if (s.tw_off >= 0 && s.tw_mod > 1) {
+        if (s.tw_div % R) ok = false;
+        else { const i64 kdiv = s.tw_div / R; if (phi % kdiv || (phi / kdiv) % s.tw_mod) ok = false; }
+      }
+    }
+    if (!ok) { for (size_t k = a; k < b; ++k) out.push_back(st[k]); a = b; continue; }
+    const int mat = pool.per_comp([&](int t, std::vector<u64>& o) {
+      const u64 q = qs[(size_t)t];
+      const std::vector<u64>& tab = pool.pool[(size_t)t];
+      std::vector<u64> y((size_t)phi), v, w;
+      for (i64 c = 0; c < phi; ++c) {
+        std::fill(y.begin(), y.end(), 0); y[(size_t)c] = 1 % q;
+        for (size_t k = a; k < b; ++k) {
+          const Stage& s = st[k];
+          const i64 d = s.d, stride = s.rts / R;
+          v.assign((size_t)d, 0); w.assign((size_t)d, 0);
+          for (i64 blk = 0; blk < phi / (d * stride); ++blk)
+            for (i64 r = 0; r < stride; ++r) {
+              const i64 x0 = blk * d * stride + r;
+              for (i64 i = 0; i < d; ++i) v[(size_t)i] = y[(size_t)(x0 + i * stride)];
+              for (i64 i = 0; i < d; ++i) {
+                u64 acc = 0;
+                for (i64 j = 0; j < d; ++j) acc = (acc + mulmod(tab[(size_t)(s.mat_off + i * d + j)] % q, v[(size_t)j], q)) % q;
+                if (s.tw_off >= 0) {
+                  const i64 xl = x0 + i * stride;
+                  const i64 idx = s.tw_mod > 1 ? (xl / (s.tw_div / R)) % s.tw_mod : 0;
+                  acc = mulmod(acc, tab[(size_t)(s.tw_off + idx)] % q, q);
+                }
+                w[(size_t)i] = acc;
+              }
+              for (i64 i = 0; i < d; ++i) y[(size_t)(x0 + i * stride)] = w[(size_t)i];
+            }
+        }
+        for (i64 i = 0; i < phi; ++i) o[(size_t)(i * phi + c)] = y[(size_t)i];
+      }
+    }, (size_t)(phi * phi));
+    Stage m;
+    std::memset(&m, 0, sizeof(m));
+    m.kind = inv ? ST_CRTPINV : ST_CRTP; m.p = p; m.d = (int32_t)phi; m.rts = (int32_t)R; m.wp_off = st[a].wp_off;
+    m.tw_off = -1; m.tw_mod = 1; m.tw_div = 1; m.mat_off = mat;
+    out.push_back(m);
+    any = true;
+    a = b;
+  }
+  if (any) st.swap(out);
+  return any;
+}
+
 int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>& qs,
                     const u64* omega_pp_in, const i64* mhatinv_in) {
   if (!valid_pps(pps) || qs.empty() || qs.size() > 64) return LOLHIP_ERR_INVALID;
@@ -302,6 +377,14 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     return pool.add(tab);
   };
 
+  // class 2 of the vector interpreter (as plan_upload decides it), and the longest dense vector its one
+  // 64-bit accumulator and 32-bit Montgomery step (mixed_impl.h redc64) take: D q^2 < 2^64 and D q <= 2^34
+  bool cls2 = true;
+  int max_phi = 20;
+  for (u64 q : qs) {
+    if (q >= ((u64)1 << 32) || !(q & 1) || (unsigned __int128)13 * (q - 1) * (q - 1) >= ((unsigned __int128)1 << 64)) cls2 = false;
+    else if ((unsigned __int128)20 * q * q >= ((unsigned __int128)1 << 64) || 20 * q > ((u64)1 << 34)) max_phi = 13;
+  }
   ProgBuilder crt, crtinv, crt_odd, crtinv_odd;
   const bool split2 = K >= 2 && pps[0].p == 2;   // odd-only programs skip the first (2-power) factor
   {
@@ -364,7 +447,9 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
       s.tw_off = tw_off; s.tw_mod = (int32_t)h; s.tw_div = 1; s.mat_off = mat_off;
       return s;
     };
-    // level groups, bottom up: 4 levels per tile, the remainder on top
+    // level groups, bottom up: 4 levels per tile, the remainder on top.  (Five levels in the first tile of the
+    // 32-bit class — 32 residues, twiddles as scalar operands — were built: the monolithic interpreter kernel then
+    // spills 27 VGPRs at its 80-register budget and every program pays for it; profiles/r03_ab_merge.txt.)
     std::vector<std::pair<int, int>> groups;
     for (int s = 1; s <= L; s += 4) groups.push_back({s, std::min(4, L - s + 1)});
     for (auto& g : groups) fused_f.push_back(tile(ST_POW2F, g.first, g.second, twf, -1));
@@ -374,6 +459,27 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
       fused_i.push_back(tile(ST_POW2I, it->first, it->second, twi, it->first == 1 ? mh : -1));
     finish(fused_f); finish(fused_i);
     P.fused2 = true;
+  }
+  // class 2: small prime powers as one dense stage each (merge_prime_powers; plan.h says which program runs where)
+  for (StageProgram* sp : {&P.prog_crt_mg, &P.prog_crtinv_mg, &P.prog_crt_mg_big, &P.prog_crtinv_mg_big, &P.prog_crt_fused_big, &P.prog_crtinv_fused_big})
+    sp->stages.clear();
+  if (cls2 && P.has_crt && !sw(SW_NO_MERGE)) {
+    auto has_big = [](const std::vector<Stage>& st) { for (const Stage& s : st) if (s.kind != ST_POW2F && s.kind != ST_POW2I && s.d > 13) return true; return false; };
+    // both directions of a pair get the same treatment (the fused poly-mul launches them together)
+    auto merged_pair = [&](const std::vector<Stage>& f0, const std::vector<Stage>& i0, int phi, std::vector<Stage>& f, std::vector<Stage>& i) {
+      f = f0; i = i0;
+      const bool mf = merge_prime_powers(f, pool, qs, phi), mi = merge_prime_powers(i, pool, qs, phi);
+      if (mf != mi) { f = f0; i = i0; return false; }
+      if (mf) { finish(f); finish(i); }
+      return mf;
+    };
+    std::vector<Stage> f, i;
+    if (!fused_f.empty()) {
+      if (max_phi > 13 && merged_pair(fused_f, fused_i, max_phi, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_fused_big.stages = f; P.prog_crtinv_fused_big.stages = i; }
+      if (merged_pair(fused_f, fused_i, 13, f, i)) { fused_f = f; fused_i = i; }
+    }
+    if (max_phi > 13 && merged_pair(crt.st, crtinv.st, max_phi, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_mg_big.stages = f; P.prog_crtinv_mg_big.stages = i; }
+    if (merged_pair(crt.st, crtinv.st, 13, f, i)) { P.prog_crt_mg.stages = f; P.prog_crtinv_mg.stages = i; }
   }
   P.prog_crt_fused.stages = fused_f;
   P.prog_crtinv_fused.stages = fused_i;
@@ -449,6 +555,8 @@ static int upload(Tp** dptr, const std::vector<Tp>& h) {
 
 static int upload_prog(StageProgram& sp) {
   sp.nstages = (int)sp.stages.size();
+  sp.big = false;
+  for (const Stage& s : sp.stages) if (s.kind != ST_POW2F && s.kind != ST_POW2I && s.d > 13) sp.big = true;
   return upload(&sp.d_stages, sp.stages);
 }
 
@@ -462,7 +570,8 @@ int plan_upload(Plan& P) {
   if ((rc = upload(&P.d_mod, mods))) return rc;
   if ((rc = upload(&P.d_consts, P.host_consts))) return rc;
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused,
+                           &P.prog_crt_mg, &P.prog_crtinv_mg, &P.prog_crt_mg_big, &P.prog_crtinv_mg_big, &P.prog_crt_fused_big, &P.prog_crtinv_fused_big};
   for (auto* sp : progs) if ((rc = upload_prog(*sp))) return rc;
   if ((rc = upload(&P.d_cconsts, P.host_cconsts))) return rc;
   if ((rc = upload(&P.d_rconsts, P.host_rconsts))) return rc;
@@ -585,7 +694,8 @@ void plan_free_device(Plan& P) {
   fr(P.pow2.d_tw_fwd); fr(P.pow2.d_tw_inv); fr(P.pow2.d_scale);
   fr(P.pow2.d_tw_fwd32); fr(P.pow2.d_tw_inv32); fr(P.pow2.d_scale32);
   StageProgram* progs[] = {&P.prog_crt, &P.prog_crtinv, &P.prog_l, &P.prog_linv, &P.prog_gpow, &P.prog_gdec, &P.prog_ginvpow, &P.prog_ginvdec,
-                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused};
+                           &P.prog_crt_odd, &P.prog_crtinv_odd, &P.prog_gauss, &P.prog_crt_fused, &P.prog_crtinv_fused,
+                           &P.prog_crt_mg, &P.prog_crtinv_mg, &P.prog_crt_mg_big, &P.prog_crtinv_mg_big, &P.prog_crt_fused_big, &P.prog_crtinv_fused_big};
   for (auto* sp : progs) { fr(sp->d_stages); sp->d_stages = nullptr; }
   P.d_mod = nullptr; P.d_consts = nullptr; P.d_gcrt = nullptr; P.d_ginvcrt = nullptr;
   P.pow2 = Pow2Tables();

@@ -60,6 +60,7 @@ struct StageProgram {
   std::vector<Stage> stages;   // host copy
   Stage* d_stages = nullptr;   // device copy
   int nstages = 0;
+  bool big = false;            // holds a dense vector longer than 13 (merged 3^3 / 5^2): the BIG kernels of class 2 only
 };
 
 // ---- power-of-two fast path -------------------------------------------------
@@ -109,6 +110,12 @@ struct Plan {
   // reference's own parameter sets (64*27, 64*81, 64*9*25, 128*7*13 ...) a fused 3-pass kernel.
   bool fused2 = false;
   StageProgram prog_crt_fused, prog_crtinv_fused;
+  // class 2 of the vector interpreter: prime powers of small totient as ONE dense stage each (plan.cpp
+  // merge_prime_powers).  Totients up to 13 (3^2) run in every kernel: prog_crt_fused / prog_crtinv_fused are merged
+  // in place, prog_crt_mg / prog_crtinv_mg are the merged copies of prog_crt / prog_crtinv (empty when nothing
+  // merges).  Totients 18 and 20 (3^3, 5^2) need the BIG kernels (mixed_impl.h): the *_big programs, empty when they
+  // would equal the others; lone transforms and the fused poly-mul take them, the fused key switch does not.
+  StageProgram prog_crt_mg, prog_crtinv_mg, prog_crt_mg_big, prog_crtinv_mg_big, prog_crt_fused_big, prog_crtinv_fused_big;
   i64* d_gcrt = nullptr;                    // [n*T]
   i64* d_ginvcrt = nullptr;                 // [n*T]
   Pow2Tables pow2;
@@ -148,7 +155,7 @@ void plan_free_device(Plan& P);
 // A/B switches of the launch paths (development and tests): read ONCE from the environment
 // (LOLHIP_<NAME>) into atomics; tests flip them through lolhip_debug_set, never through setenv
 // (getenv racing with setenv is undefined behaviour, and plans are used from concurrent threads).
-enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_COUNT };
+enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_NO_MERGE, SW_COUNT };
 bool sw(Switch which);
 inline bool pow2_no_t1() { return sw(SW_NO_T1); }
 

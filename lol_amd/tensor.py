@@ -460,6 +460,10 @@ class Plan:
     def gCRT(self): return self._table(3).reshape(self.n, self.T)
     def gInvCRT(self): return self._table(4).reshape(self.n, self.T)
 
+    def program(self, inverse=False):
+        """Stage program of a lone crt / crtInv (inspection): rows (kind, prime or first level, length or levels, stride)."""
+        return self._table(11 if inverse else 10).reshape(-1, 4)
+
     # ---- helpers ------------------------------------------------------------------
     def _batch(self, a):
         per = self.n * self.T

@@ -294,6 +294,32 @@ def test_generic_indices(gpu, cpuref, m):
         assert np.array_equal(P.divGCRT(P.mulGCRT(y)), y)
 
 
+@pytest.mark.parametrize("m", [9, 25, 27, 45, 225, 675, 1575, 1728, 3200, 14400, 192, 384, 3072, 6144, 11648])
+def test_merged_prime_powers(gpu, cpuref, m):
+    """Class 2 of the vector interpreter (32-bit residues, one 64-bit accumulator per dot product): the plan
+    replaces CRT_{p^e} for 3^2, 5^2, 3^3 by ONE dense phi x phi stage (plan.cpp merge_prime_powers).  Same linear maps, so the same residues: against the
+    oracle and against a plan built with it turned off (NO_MERGE), at a modulus that takes the 20-term
+    accumulator (q < 2^29.68), one that only takes 13 terms (3^2 merges, 5^2 and 3^3 stay staged) and two moduli
+    per plan; crt, crtInv, poly-mul, squaring, ragged batch."""
+    pps = lm.factor_pps(m)
+    for qs in ([lm.first_good_q(m, 2 ** 20)], [lm.first_good_q(m, 2 ** 29)], [lm.first_good_q(m, 2 ** 30)],
+               [lm.first_good_q(m, 2 ** 26), lm.first_good_q(m, 2 ** 29 + 2 ** 28)]):
+        R = Params(pps, qs)
+        rng = np.random.default_rng(m + len(qs))
+        B = 5 if R.n <= 2000 else 2
+        y, z = R.random(rng, B), R.random(rng, B)
+        want = cpuref.crt(R, y), cpuref.crtinv(R, y), cpuref.polymul(R, y, z), cpuref.polymul(R, y, y)
+        for merged in (True, False):
+            gpu.debug_set("NO_MERGE", not merged)
+            P = gpu.Plan(pps, qs)
+            gpu.debug_set("NO_MERGE", False)
+            assert np.array_equal(P.crt(y), want[0]), (m, qs, merged)
+            assert np.array_equal(P.crtInv(y), want[1]), (m, qs, merged)
+            assert np.array_equal(P.polymul(y, z), want[2]), (m, qs, merged)
+            assert np.array_equal(P.polymul(y, y), want[3]), (m, qs, merged)
+            assert np.array_equal(P.crtInv(P.crt(y)), y)
+
+
 @pytest.mark.parametrize("m", [12, 40, 48, 96, 160, 768, 1728, 2912, 11648, 14336, 2 ** 12 * 3])
 def test_two_power_factor_routes(gpu, cpuref, monkeypatch, m):
     """m = 2^e * odd: the innermost tensor factor CRT_{2^e} acts on contiguous blocks of 2^(e-1)

@@ -141,3 +141,24 @@ def test_device_code_has_no_unpadded_wide_store(lolhip):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 unpadded store-data pair(s)" in r.stdout
+
+
+def test_class2_plans_merge_small_prime_powers():
+    """plan.cpp merge_prime_powers / tile grouping, on host-only plans (no GPU): what a lone crt of the
+    reference's benchmark index 64*9*25 (Benchmarks/Default.hs:49-50) launches.  Kinds: 12/13 = 2-power tile
+    forward/inverse, 1 = DFT_p, 2 = CRT_p, 3 = CRT_p^-1 (plan.h)."""
+    import lol_amd
+    def prog(q, inverse=False, m=14400):
+        return [tuple(int(v) for v in r) for r in lol_amd.Plan(lm.factor_pps(m), [q], host_only=True).program(inverse)]
+    q26, q30, q45 = (lm.first_good_q(14400, 2 ** b) for b in (26, 30, 45))
+    assert prog(q26) == [(12, 1, 4, 1), (12, 5, 1, 16), (2, 3, 6, 32), (2, 5, 20, 192)]
+    assert prog(q26, True) == [(3, 3, 6, 32), (3, 5, 20, 192), (13, 5, 1, 16), (13, 1, 4, 1)]      # tensor factors commute: same order of primes
+    # 20 (q-1)^2 no longer fits 64 bits: 5^2 stays staged, 3^2 (6 terms) still merges
+    assert prog(q30) == [(12, 1, 4, 1), (12, 5, 1, 16), (2, 3, 6, 32), (2, 5, 4, 192), (1, 5, 5, 768)]
+    # 64-bit residues: the staged form, four levels per tile
+    assert prog(q45) == [(12, 1, 4, 1), (12, 5, 1, 16), (2, 3, 2, 32), (1, 3, 3, 64), (2, 5, 4, 192), (1, 5, 5, 768)]
+    lol_amd.debug_set("NO_MERGE", True)
+    try:
+        assert prog(q26) == prog(q45)
+    finally:
+        lol_amd.debug_set("NO_MERGE", False)
