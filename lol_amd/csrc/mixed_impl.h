@@ -146,6 +146,82 @@ __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const PT<CLS>* _
   }
 }
 
+// Class 3 (64-bit residues: one multiply-accumulate is ~8 instructions): DFT_p, CRT_p and the scaled CRT_p^-1 of an odd
+// prime in their even/odd form.  With w = omega_p, h = (p-1)/2, e_c = x_c + x_(p-c), o_c = x_c - x_(p-c) (c = 1..h; a
+// position the vector does not have counts as 0):
+//   sum_c x_c w^(rc)  =  x_0 + S_r + A_r,   sum_c x_c w^(-rc)  =  x_0 + S_r - A_r,
+//   S_r = sum_c e_c (w^(rc) + w^(-rc))/2,   A_r = sum_c o_c (w^(rc) - w^(-rc))/2          (r = 1..h)
+// so rows r and p-r share their products: 2 h^2 multiply-accumulates instead of (p-1)^2 (72 instead of 144 at p = 13),
+// the same number of Montgomery reductions, and ~3 modular additions per output.  Exact arithmetic in Z_q: the same
+// residues as the dense form (crt.cpp:226-245, 324-345, 433-456).  Tables: plan.cpp (Stage::pad[0]); e is canonical
+// where it is also summed, o = x + q - y stays below 2q: every accumulator is below 2 h q^2 <= 12 q^2 (redc128: < 13 q^2).
+template <int D>
+__device__ __forceinline__ void apply_eo(const Stage& st, const u64 (&v)[D], u64 (&o)[D], const u64* __restrict__ cst, const ModCtx& mc) {
+  constexpr bool DFT = (D & 1) != 0;
+  constexpr int P = DFT ? D : D + 1, H = (P - 1) / 2;
+  const u64 q = mc.q;
+  const u64* Cs = cst + st.pad[0];
+  const u64* Sn = Cs + H * H;
+  const bool inv = !DFT && st.kind == ST_CRTPINV;
+  // x_k for k = 0..P-1 in terms of the vector: DFT x_k = v[k]; CRT_p x_k = v[k], x_(P-1) = 0; CRT_p^-1 x_k = v[k-1], x_0 = 0
+  u64 e[H + 1], od[H + 1];
+#pragma unroll
+  for (int c = 1; c <= H; ++c) {
+    u64 a, b;
+    bool lone = false;                              // CRT_p: x_(P-1) does not exist
+    if (DFT) { a = v[c]; b = v[P - c]; }
+    else if (inv) { a = v[c - 1]; b = v[P - c - 1]; }
+    else { a = v[c]; lone = (c == 1); b = lone ? 0 : v[P - c]; }
+    e[c] = lone ? a : addmod(a, b, q);
+    od[c] = lone ? a : a + (q - b);
+  }
+  // one row pair at a time, its outputs finished before the next pair's products start (no S/A arrays: the fused
+  // poly-mul of this class has ~64 VGPRs to spare)
+  auto pair = [&](int r, u64& S, u64& A) {
+    unsigned __int128 as = 0, aa = 0;
+#pragma unroll
+    for (int c = 1; c <= H; ++c) {
+      as += (unsigned __int128)e[c] * Cs[(r - 1) * H + (c - 1)];
+      aa += (unsigned __int128)od[c] * Sn[(r - 1) * H + (c - 1)];
+    }
+    S = redc128(as, mc);
+    A = redc128(aa, mc);
+  };
+  if (!inv) {
+    const u64 x0 = v[0];
+    if constexpr (DFT) {
+      u64 s0 = x0;
+#pragma unroll
+      for (int c = 1; c <= H; ++c) s0 = addmod(s0, e[c], q);
+      o[0] = s0;
+    }
+    constexpr int SH = DFT ? 0 : 1;                 // CRT_p: output i is row i + 1
+#pragma unroll
+    for (int r = 1; r <= H; ++r) {
+      u64 S, A;
+      pair(r, S, A);
+      const u64 t = addmod(S, x0, q);
+      o[r - SH] = addmod(t, A, q);
+      o[P - r - SH] = submod(t, A, q);
+    }
+  } else {
+    // M[i][c] = w^(i (c+1)) - w^(-(c+1)): row i of the transform minus C = sum_k x_k w^(-k) = S_1 - A_1 (row p-1)
+    u64 s0 = 0;
+#pragma unroll
+    for (int c = 1; c <= H; ++c) s0 = addmod(s0, e[c], q);
+    u64 C = 0;
+#pragma unroll
+    for (int i = 1; i <= H; ++i) {
+      u64 S, A;
+      pair(i, S, A);
+      if (i == 1) { C = submod(S, A, q); o[0] = submod(s0, C, q); }
+      const u64 t = submod(S, C, q);
+      o[i] = addmod(t, A, q);
+      if (i >= 2) o[P - i] = submod(t, A, q);
+    }
+  }
+}
+
 // the linear map of one stage on one d-vector in registers: o = A v
 template <int CLS, int D>
 __device__ __forceinline__ void apply_kind(const Stage& st, const MV<CLS> (&v)[D], MV<CLS> (&o)[D],
@@ -158,6 +234,9 @@ __device__ __forceinline__ void apply_kind(const Stage& st, const MV<CLS> (&v)[D
     case ST_DFTP:
     case ST_CRTP:
     case ST_CRTPINV: {
+#ifndef LH_NO_EO
+      if constexpr (CLS == 3 && D >= 3 && D <= 13) { apply_eo<D>(st, v, o, cst, mc); break; }      // every class-3 plan carries the tables (plan.cpp finish)
+#endif
       const PT<CLS>* M = cst + st.mat_off;
 #pragma unroll
       for (int i = 0; i < D; ++i) o[i] = m_dot<CLS, D>(v, M + i * D, mc);

@@ -357,8 +357,18 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
 
   // ---- generic stage programs + constant pool ---------------------------------
   auto magic40 = [](i64 v) -> uint64_t { return (uint64_t)(((unsigned __int128)1 << 40) / (uint64_t)(v > 0 ? v : 1)) + 1; };
-  auto finish = [&](std::vector<Stage>& st) {
+  // class 3 of the vector interpreter (as plan_upload decides it): the dense stages of odd primes take the
+  // even/odd form (mixed_impl.h apply_eo) — eo_off[p][direction] is filled below, before any program is finished
+  bool cls3 = true;
+  { bool fits32 = true;
+    for (u64 q : qs) { if (q >= ((u64)1 << 32)) fits32 = false; if (!(q & 1) || q >= ((u64)1 << 61)) cls3 = false; }
+    if (fits32) cls3 = false; }
+  int eo_off[16][2];
+  for (auto& r : eo_off) r[0] = r[1] = 0;
+  auto finish = [&](std::vector<Stage>& st, bool inverse = false) {
     for (auto& s : st) {
+      const bool dense_odd = (s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV) && s.p > 2 && s.p <= 13 && s.d >= 3 && (s.d == s.p || s.d == s.p - 1);
+      s.pad[0] = (cls3 && dense_odd) ? eo_off[s.p][inverse ? 1 : 0] : 0;
       s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod);
       const bool dense = s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV;
       s.tw_per = (!sw(SW_NO_OWN_DIAG) && dense && s.tw_off >= 0 && s.tw_mod > 1 && s.tw_div == s.rts && s.tw_mod % s.d == 0) ? s.tw_mod / s.d : 0;
@@ -392,6 +402,27 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     build_crt_programs(pps, ring, pool, &crt, &crtinv, split2 ? &crt_odd : nullptr, split2 ? &crtinv_odd : nullptr);
   }
   const int orad_off = per_comp([&](int t, std::vector<u64>& o) { o[0] = P.oddrad_inv[(size_t)t]; }, 1);
+  // even/odd tables of the odd primes (class 3): for r, c = 1 .. h = (p-1)/2 and w = omega_p (inverse: omega_p^-1)
+  //   cos[r][c] = (w^(rc) + w^(-rc)) / 2,   sin[r][c] = (w^(rc) - w^(-rc)) / 2      (q odd), cos first, row-major
+  if (cls3 && P.has_crt) {
+    for (int k = 0; k < K; ++k) {
+      const int p = pps[(size_t)k].p;
+      if (p < 3 || p > 13) continue;
+      const i64 mprime = ipow(p, pps[(size_t)k].e - 1);
+      const int h = (p - 1) / 2;
+      for (int inv = 0; inv < 2; ++inv)
+        eo_off[p][inv] = per_comp([&](int t, std::vector<u64>& o) {
+          const u64 q = qs[(size_t)t], half = (q + 1) >> 1;
+          auto w = [&](i64 ex) { return (u64)(inv ? P.ruinv : P.ru)[(size_t)k][(size_t)((((ex % p) + p) % p) * mprime * T + t)]; };
+          for (int r = 1; r <= h; ++r)
+            for (int c = 1; c <= h; ++c) {
+              const u64 a = w((i64)r * c), b = w(-(i64)r * c);
+              o[(size_t)((r - 1) * h + (c - 1))] = mulmod((a + b) % q, half, q);
+              o[(size_t)(h * h + (r - 1) * h + (c - 1))] = mulmod((a + q - b) % q, half, q);
+            }
+        }, (size_t)(2 * h * h));
+    }
+  }
 
   auto prime_prog = [&](int kind, bool scale) {
     ProgBuilder pb;
@@ -405,7 +436,7 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     finish(pb.st);
     return pb.st;
   };
-  finish(crt.st); finish(crtinv.st);
+  finish(crt.st, false); finish(crtinv.st, true);
   P.prog_crt.stages = crt.st;
   P.prog_crtinv.stages = crtinv.st;
   P.prog_l.stages = prime_prog(ST_L, false);
@@ -457,7 +488,7 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     fused_i = crtinv_odd.st;
     for (auto it = groups.rbegin(); it != groups.rend(); ++it)
       fused_i.push_back(tile(ST_POW2I, it->first, it->second, twi, it->first == 1 ? mh : -1));
-    finish(fused_f); finish(fused_i);
+    finish(fused_f, false); finish(fused_i, true);
     P.fused2 = true;
   }
   // class 2: small prime powers as one dense stage each (merge_prime_powers; plan.h says which program runs where)
@@ -470,7 +501,7 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
       f = f0; i = i0;
       const bool mf = merge_prime_powers(f, pool, qs, phi), mi = merge_prime_powers(i, pool, qs, phi);
       if (mf != mi) { f = f0; i = i0; return false; }
-      if (mf) { finish(f); finish(i); }
+      if (mf) { finish(f, false); finish(i, true); }
       return mf;
     };
     std::vector<Stage> f, i;
@@ -533,7 +564,7 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   P.pow2_part = P.has_crt && K >= 2 && pps[0].p == 2 && pps[0].e >= 5 && pps[0].e <= 15;
   P.pow2.L = (P.is_pow2 || P.pow2_part) ? pps[0].e - 1 : 0;
   if (P.pow2_part) {        // mhat^-1 is not in crtinv_odd: the 2-power inverse kernel folds it in
-    finish(crt_odd.st); finish(crtinv_odd.st);
+    finish(crt_odd.st, false); finish(crtinv_odd.st, true);
     P.prog_crt_odd.stages = crt_odd.st;
     P.prog_crtinv_odd.stages = crtinv_odd.st;
   }
