@@ -519,11 +519,13 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !sw(SW_KEYSWITCH_UNFUSED)) {
     const bool fused2 = use_fused2(P);
     const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);
-    const StageProgram& pf = fused2 ? fused_crt(P, false) : zq_crt(P, false);      // the key-switch kernel holds two accumulator sets: no 20-element vectors
+    // the key-switch kernel holds two accumulator sets per coefficient: 20-element vectors only at <= 12 coefficients per thread
+    const bool big_ok = mixed_keyswitch_big_ok(P.n);
+    const StageProgram& pf = fused2 ? fused_crt(P, big_ok) : zq_crt(P, big_ok);
     if (!split2 && (fused2 || use_mixed(P, pf))) {
       MixedKeySwitchLaunch l;
       l.stream = stream; l.c2 = c2_pow; l.hint = hint; l.addend = addend; l.out = out; l.B = B; l.T = P.T; l.n = P.n;
-      l.st_crt = pf.d_stages; l.n_crt = pf.nstages; l.consts32 = P.d_consts32; l.cpc = P.consts_per_comp; l.mod = P.d_mod; l.dp = d;
+      l.st_crt = pf.d_stages; l.n_crt = pf.nstages; l.big = pf.big; l.consts32 = P.d_consts32; l.cpc = P.consts_per_comp; l.mod = P.d_mod; l.dp = d;
       l.magic32 = 1;
       if (base >= 2) {
         int lg = 0;

@@ -100,7 +100,9 @@ struct MixedKeySwitchLaunch {
   const ModCtx* mod;
   DecompParams dp;
   uint32_t magic32;     // 32-bit invariant-divisor constant of dp.base
+  bool big = false;     // st_crt holds 18-/20-element vectors: only where mixed_keyswitch_big_ok(n)
 };
+bool mixed_keyswitch_big_ok(i64 n);
 hipError_t launch_mixed_keyswitch(const MixedKeySwitchLaunch& a);
 hipError_t launch_mixed(const MixedLaunch& a);
 

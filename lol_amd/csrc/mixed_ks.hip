@@ -22,7 +22,9 @@ namespace lolhip {
 __device__ __forceinline__ u32 load_lo32(rsrc_t r, u32 voff, u32 soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
 __device__ __forceinline__ u32 canon_lo32(u32 x, u32 q) { return x + (q & (u32)((int)x >> 31)); }
 
-template <int KMAX>
+// BIG: the stage program may hold the 18-/20-element vectors of merged prime powers (mixed_impl.h run_stages);
+// instantiated for <= 12 coefficients per thread only (the accumulator sets of 16 leave no room for a 20-vector)
+template <int KMAX, bool BIG = false>
 __global__ void __launch_bounds__(512, 4)
 k_mixed_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, const i64* addend, i64* out, i64 B, int T, int n,
                   const Stage* __restrict__ st_crt, int n_crt, const u32* __restrict__ consts32, int cpc,
@@ -98,7 +100,7 @@ k_mixed_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, cons
           }
         }
         __syncthreads();
-        run_stages<CLS, false>(buf, n, n, n_magic, st_crt, n_crt, cst, ms);      // ends with a barrier
+        run_stages<CLS, false, BIG>(buf, n, n, n_magic, st_crt, n_crt, cst, ms);      // ends with a barrier
         {
           const u32 hoff = (u32)j * 2u * pbytes + (u32)s * 8u;
           const int x0 = fresh(tid);
@@ -146,20 +148,25 @@ k_mixed_keyswitch(const i64* __restrict__ c2, const i64* __restrict__ hint, cons
 
 // does the fused kernel take this key switch?  (class-2 plan of the vector interpreter, two hint coefficients,
 // a base whose digits fit 32-bit arithmetic, hints addressable through one buffer descriptor)
+static int ks_threads(i64 n) { return n > 2048 ? 512 : (n > 1024 ? 256 : 128); }
+// may this key switch run a program with 18-/20-element vectors?  (at most 12 coefficients per thread)
+bool mixed_keyswitch_big_ok(i64 n) { return ((size_t)n + ks_threads(n) - 1) / ks_threads(n) <= 12; }
+
 hipError_t launch_mixed_keyswitch(const MixedKeySwitchLaunch& a) {
   if (a.B == 0) return hipSuccess;
   const size_t lds_bytes = (size_t)a.n * sizeof(u32);
   // few coefficients per thread: the two accumulator sets (4 VGPRs per coefficient) stay in registers across the stage program
-  const int threads = a.n > 2048 ? 512 : (a.n > 1024 ? 256 : 128);
+  const int threads = ks_threads(a.n);
   i64 grid = a.B * a.T;
   if (grid > 65536) grid = 65536;
   const size_t per_thread = ((size_t)a.n + threads - 1) / threads;
-#define LOLHIP_KS_LAUNCH(K)                                                                                             \
-  hipLaunchKernelGGL((k_mixed_keyswitch<K>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.c2, a.hint,   \
+#define LOLHIP_KS_LAUNCH(K, BIG)                                                                                           \
+  hipLaunchKernelGGL((k_mixed_keyswitch<K, BIG>), dim3((unsigned)grid), dim3(threads), lds_bytes, a.stream, a.c2, a.hint,  \
                      a.addend, a.out, a.B, a.T, (int)a.n, a.st_crt, a.n_crt, a.consts32, a.cpc, a.mod, a.dp, a.magic32)
-  if (per_thread <= 8) LOLHIP_KS_LAUNCH(8);
-  else if (per_thread <= 12) LOLHIP_KS_LAUNCH(12);
-  else LOLHIP_KS_LAUNCH(16);
+  if (a.big && per_thread > 12) return hipErrorInvalidValue;      // the caller picks the program (mixed_keyswitch_big_ok)
+  if (per_thread <= 8) { if (a.big) LOLHIP_KS_LAUNCH(8, true); else LOLHIP_KS_LAUNCH(8, false); }
+  else if (per_thread <= 12) { if (a.big) LOLHIP_KS_LAUNCH(12, true); else LOLHIP_KS_LAUNCH(12, false); }
+  else LOLHIP_KS_LAUNCH(16, false);
 #undef LOLHIP_KS_LAUNCH
   return hipGetLastError();
 }

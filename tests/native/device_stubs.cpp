@@ -12,6 +12,7 @@ hipError_t launch_generic(const GenericLaunch&) { return hipErrorNoDevice; }
 bool mixed_ok(i64, const Stage*, int, const u64*, int) { return false; }
 hipError_t launch_mixed(const MixedLaunch&) { return hipErrorNoDevice; }
 hipError_t launch_mixed_keyswitch(const MixedKeySwitchLaunch&) { return hipErrorNoDevice; }
+bool mixed_keyswitch_big_ok(i64) { return false; }
 hipError_t launch_cplx(hipStream_t, double*, i64, i64, const Stage*, int, const double*) { return hipErrorNoDevice; }
 hipError_t launch_gauss(hipStream_t, double*, i64, i64, const Stage*, int, const double*) { return hipErrorNoDevice; }
 hipError_t launch_pointwise_mul(hipStream_t, i64*, const i64*, i64, i64, int, const ModCtx*) { return hipErrorNoDevice; }
