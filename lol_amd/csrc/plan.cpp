@@ -480,7 +480,9 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     };
     // level groups, bottom up: 4 levels per tile, the remainder on top.  (Five levels in the first tile of the
     // 32-bit class — 32 residues, twiddles as scalar operands — were built: the monolithic interpreter kernel then
-    // spills 27 VGPRs at its 80-register budget and every program pays for it; profiles/r03_ab_merge.txt.)
+    // spills 27 VGPRs at its 80-register budget; in separate instantiations at 128 registers it does not spill and the
+    // lone crt of 64*9*25 is 14 % SLOWER — 120 work items of 32 coefficients idle half the workgroup and serialise
+    // each stage; profiles/r03_ab_tile5_negative.txt.)
     std::vector<std::pair<int, int>> groups;
     for (int s = 1; s <= L; s += 4) groups.push_back({s, std::min(4, L - s + 1)});
     for (auto& g : groups) fused_f.push_back(tile(ST_POW2F, g.first, g.second, twf, -1));
