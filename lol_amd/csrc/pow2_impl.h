@@ -181,6 +181,49 @@ __device__ __forceinline__ u32 csub32(u32 x, u32 m) { return min(x, x - m); }   
 // w*y mod q in [0,2q) for any 32-bit y
 __device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return w * y - __umulhi(wp, y) * q; }
 
+// ---- pair/mad form of the 32-bit lazy butterflies (LOLHIP_PAIR_BFLY: pow2_pipe.hip only) -----------------------
+// A residue sits in the LOW half of a 64-bit register pair (the high half is never read), so v_mad_u64_u32 does the
+// multiply AND the add: x + w y - Q q as two chained mads (nq = -q mod 2^32), 2x + 2q - X' as a mad by -1.  Forward 5
+// instructions instead of 7, inverse 7 instead of 9; the same values mod 2^32 as the 32-bit forms below, so the same
+// lazy ranges.  Twice the data registers: for the persistent kernel (4 waves per SIMD), not the 8-wave ones.
+// tools/microbench_bfly32.hip: -13 % / -6 % per butterfly, exact.
+#ifndef LOLHIP_PAIR_BFLY
+#define LOLHIP_PAIR_BFLY 0
+#endif
+__device__ __forceinline__ u64 pair_of(u32 lo) { typedef u32 u32p __attribute__((ext_vector_type(2))); u32p t; t.x = lo; return __builtin_bit_cast(u64, t); }
+// X' = x + w Y - Q q,  Y' = 2x + 2q - X'   (x, Y any 32-bit values)
+template <bool WS>
+__device__ __forceinline__ void fwd_pair(u32& X, u32& Y, u32 x, u32 w, u32 wp, u32 q, u32 q2) {
+  const u64 xp = pair_of(x), q2p = (u64)q2;
+  const u32 nq = 0u - q;
+  u64 Xn, Z, Yn, cy; u32 Q;
+#define LH_FWD_PAIR(WC)                                                                                     \
+  asm("v_mul_hi_u32 %[Q], %[wp], %[yl]\n\t"                                                                  \
+      "v_mad_u64_u32 %[Xn], %[cy], %[w], %[yl], %[X]\n\t"                                                    \
+      "v_lshl_add_u64 %[Z], %[X], 1, %[q2]\n\t"                                                              \
+      "v_mad_u64_u32 %[Xn], %[cy], %[Q], %[nq], %[Xn]"                                                        \
+      : [Q] "=&v"(Q), [Xn] "=&v"(Xn), [Z] "=&v"(Z), [cy] "=&s"(cy)                                            \
+      : [wp] WC(wp), [yl] "v"(Y), [w] WC(w), [X] "v"(xp), [q2] "s"(q2p), [nq] "s"(nq))
+  if constexpr (WS) { LH_FWD_PAIR("s"); } else { LH_FWD_PAIR("v"); }
+#undef LH_FWD_PAIR
+  asm("v_mad_u64_u32 %[Yn], %[cy], %[xl], -1, %[Z]" : [Yn] "=v"(Yn), [cy] "=s"(cy) : [xl] "v"((u32)Xn), [Z] "v"(Z));
+  X = (u32)Xn; Y = (u32)Yn;
+}
+// w d - Q q for any 32-bit d
+template <bool WS>
+__device__ __forceinline__ u32 shoup_pair(u32 d, u32 w, u32 wp, u32 q) {
+  const u32 nq = 0u - q;
+  const u32 Q = __umulhi(wp, d);
+  u64 T, Yn, cy;
+#define LH_SH_PAIR(WC)                                                                                      \
+  asm("v_mad_u64_u32 %[T], %[cy], %[w], %[d], 0\n\t"                                                         \
+      "v_mad_u64_u32 %[Yn], %[cy], %[Q], %[nq], %[T]"                                                         \
+      : [T] "=&v"(T), [Yn] "=&v"(Yn), [cy] "=&s"(cy) : [w] WC(w), [d] "v"(d), [Q] "v"(Q), [nq] "s"(nq))
+  if constexpr (WS) { LH_SH_PAIR("s"); } else { LH_SH_PAIR("v"); }
+#undef LH_SH_PAIR
+  return (u32)Yn;
+}
+
 // forward (Cooley-Tukey) butterfly:  X' = X + w*Y,  Y' = X - w*Y
 // WS: the twiddle is wave-uniform (SGPR operands in the 64-bit class's multiply chains, zq_dev.h)
 template <int AR, bool WS = false>
@@ -192,14 +235,22 @@ __device__ __forceinline__ void bfly_fwd(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     Y = x - t + k.q;                                  // (0,2q)
   } else if constexpr (AR == 2) {
     const u32 x = csub32(X, k.q2);                    // [0,4q) -> [0,2q)
+#if LOLHIP_PAIR_BFLY
+    fwd_pair<WS>(X, Y, x, w, wp, k.q, k.q2);
+#else
     const u32 t = shoup32(Y, w, wp, k.q);
     X = x + t;
     Y = x - t + k.q2;
+#endif
   } else if constexpr (AR == 4) {
+#if LOLHIP_PAIR_BFLY
+    fwd_pair<WS>(X, Y, X, w, wp, k.q, k.q2);
+#else
     const u32 t = shoup32(Y, w, wp, k.q);             // [0,2q) for ANY 32-bit Y
     const u32 x = X;                                  // < B: both outputs < B + 2q, never wrapping below 29 q
     X = x + t;
     Y = x - t + k.q2;
+#endif
   } else if constexpr (AR == 1) {
 #ifdef LH_ABL_NO_FWD_CSUB
     const u64 x = X;                                  // timing-only ablation: results are garbage
@@ -229,7 +280,11 @@ __device__ __forceinline__ void bfly_inv(VT<AR>& X, VT<AR>& Y, VT<AR> w, VT<AR> 
     const u32 s = X + Y;
     const u32 d = X - Y + k.q2;
     X = csub32(s, k.q2);
+#if LOLHIP_PAIR_BFLY
+    Y = shoup_pair<WS>(d, w, wp, k.q);
+#else
     Y = shoup32(d, w, wp, k.q);
+#endif
   } else if constexpr (AR == 1) {
     const u64 s = add64(X, Y);                        // [0,8q)
     const u64 d = add64u(X, k.q4) - Y;                 // (0,8q)

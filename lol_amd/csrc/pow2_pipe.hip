@@ -30,6 +30,10 @@
 // pieces; the level-10 twiddles are ready at vmcnt(14 + 16), the rest at vmcnt(16), the DMA at vmcnt(0).  Every
 // asm vector-memory statement opens with s_nop 4: its SGPR operands may just have been restored from a spill lane
 // by v_readlane, and hipcc pads nothing inside an asm string.
+// (LOLHIP_PAIR_BFLY=1: the pair/mad butterflies of pow2_impl.h — built and measured in this kernel: 16 % fewer VALU
+// instructions, but at its 113-123 VGPRs the doubled data registers spill 10 of them to scratch, whose vector-memory
+// traffic lands in the hand-counted vmcnt windows: 0.253 -> 0.264 ms at q < 2^27, no change at q < 2^30;
+// profiles/r03_ab_pair_bfly_negative.txt.  Off.)
 #include "pow2_impl.h"
 #include <cstdio>
 #include <cstdlib>
