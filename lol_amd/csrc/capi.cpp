@@ -25,7 +25,7 @@ using namespace lolhip;
 namespace lolhip {
 namespace {
 const char* const kSwitchNames[SW_COUNT] = {"GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED",
-                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE"};
+                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE", "NO_LAZY"};
 std::atomic<int> g_switch[SW_COUNT];
 std::once_flag g_switch_once;
 void switches_init() {
@@ -515,7 +515,7 @@ int keyswitch_impl(const Plan& P, hipStream_t stream, const int64_t* c2_pow, int
     return launch_keyswitch_fused(l) == hipSuccess ? LOLHIP_OK : LOLHIP_ERR_HIP;
   }
   // ... and for every other index the vector interpreter takes, in its 32-bit Montgomery class (mixed_ks.hip)
-  if (!P.is_pow2 && P.mixed_cls == 2 && P.d_consts32 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
+  if (!P.is_pow2 && (P.mixed_cls == 2 || P.mixed_cls == 4) && P.d_consts32 && K == 2 && (base == 0 || base < ((int64_t)1 << 31)) &&
       (u64)d.L * 2 * (u64)P.n * (u64)P.T * 8 < ((u64)1 << 32) && !sw(SW_KEYSWITCH_UNFUSED)) {
     const bool fused2 = use_fused2(P);
     const bool split2 = !fused2 && P.pow2_part && !sw(SW_NO_POW2_PART);

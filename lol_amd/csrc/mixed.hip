@@ -11,6 +11,8 @@ LOLHIP_EXT(0) LOLHIP_EXT(1) LOLHIP_EXT(2) LOLHIP_EXT(3)
 #undef LOLHIP_EXT
 extern template hipError_t launch_cls<1, 2>(const MixedLaunch&);
 extern template hipError_t launch_cls<2, 2>(const MixedLaunch&);
+extern template hipError_t launch_cls<4, 0>(const MixedLaunch&);
+extern template hipError_t launch_cls<4, 2>(const MixedLaunch&);
 // the fused poly-mul of the 64-bit classes: one translation unit per coefficients-per-thread variant
 #define LOLHIP_EXT(C) extern template hipError_t launch_cls_k<C, 2, 12, false>(const MixedLaunch&); extern template hipError_t launch_cls_k<C, 2, 16, false>(const MixedLaunch&);
 LOLHIP_EXT(0) LOLHIP_EXT(3)
@@ -43,6 +45,7 @@ hipError_t launch_mixed(const MixedLaunch& a) {
     case 0: return a.fused ? (fused_k12(a) ? launch_cls_k<0, 2, 12>(a) : launch_cls_k<0, 2, 16>(a)) : launch_cls<0, 0>(a);
     case 1: return a.fused ? launch_cls<1, 2>(a) : launch_cls<1, 0>(a);
     case 3: return a.fused ? (fused_k12(a) ? launch_cls_k<3, 2, 12>(a) : launch_cls_k<3, 2, 16>(a)) : launch_cls<3, 0>(a);
+    case 4: return a.fused ? launch_cls<4, 2>(a) : launch_cls<4, 0>(a);
     default: return a.fused ? launch_cls<2, 2>(a) : launch_cls<2, 0>(a);
   }
 

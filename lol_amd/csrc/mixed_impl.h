@@ -48,7 +48,12 @@ template <int CLS> constexpr bool wide() { return CLS == 0 || CLS == 3; }
 #ifndef LOLHIP_MIXED_POOL32
 #define LOLHIP_MIXED_POOL32 1
 #endif
-template <int CLS> using PT = std::conditional_t<(CLS == 1 || CLS == 2) && LOLHIP_MIXED_POOL32, u32, u64>;
+template <int CLS> using PT = std::conditional_t<(CLS == 1 || CLS == 2 || CLS == 4) && LOLHIP_MIXED_POOL32, u32, u64>;
+// CLS 4 = class 2 for moduli below 2^27 with LAZY dense stages: a dot product of up to 16 terms of values below 2q has
+// T / 2^32 < q, so the Montgomery step's result h + ceil(m q / 2^32) is below 2q as it stands — 3 instructions instead
+// of the 9 of redc64 (no pre-subtraction, no canonicalising min-subtractions).  Values in [0, 2q) travel between dense
+// stages and diagonals; the 2-power tiles, the additive maps (L, G) and the store canonicalise / stay canonical.
+template <int CLS> constexpr bool c2() { return CLS == 2 || CLS == 4; }
 
 // x / v for x <= 8192 (every index here is below ppw * n <= 8192) from the plan's 2^40-scaled
 // reciprocal M = floor(2^40/v)+1: (M >> 8) + 1 is floor(2^32/v) + 1 or + 2, whose error times x
@@ -59,12 +64,12 @@ __device__ __forceinline__ int mdiv(int x, u64 M) {
 
 template <int CLS> __device__ __forceinline__ MV<CLS> m_add(MV<CLS> a, MV<CLS> b, u64 q) {
   if constexpr (wide<CLS>()) return addmod(a, b, q);
-  else if constexpr (CLS == 2) { const u32 s = a + b; return min(s, s - (u32)q); }   // q < 2^30.2: the sum fits a word
+  else if constexpr (c2<CLS>()) { const u32 s = a + b; return min(s, s - (u32)q); }   // q < 2^30.2: the sum fits a word
   else { const u64 s = (u64)a + b; return (u32)(s >= q ? s - q : s); }          // q may exceed 2^31: 33-bit sum
 }
 template <int CLS> __device__ __forceinline__ MV<CLS> m_sub(MV<CLS> a, MV<CLS> b, u64 q) {
   if constexpr (wide<CLS>()) return submod(a, b, q);
-  else if constexpr (CLS == 2) { const u32 d = a - b; return min(d, d + (u32)q); }   // a < b: d wraps high, d + q is the residue
+  else if constexpr (c2<CLS>()) { const u32 d = a - b; return min(d, d + (u32)q); }   // a < b: d wraps high, d + q is the residue
   else return a >= b ? a - b : (u32)(a + (u32)q - b);
 }
 // x mod q for a 64-bit x: Barrett with mu = floor(2^64 / q)
@@ -115,11 +120,18 @@ __device__ __forceinline__ u32 redc64_1(u64 T, const ModCtx& mc) {
   const u32 r = (u32)(T >> 32) + (u32)(((u64)m * q + 0xFFFFFFFFull) >> 32);
   return min(r, r - q);
 }
+// class 4: the bare Montgomery step.  T < 16 (2q) q with q < 2^27: T / 2^32 < q, result < 2q; same congruence as redc64
+__device__ __forceinline__ u32 redc64_lazy(u64 T, const ModCtx& mc) {
+  const u32 q = (u32)mc.q;
+  const u32 m = (u32)T * (u32)mc.nqinv;
+  return (u32)(T >> 32) + (u32)(((u64)m * q + 0xFFFFFFFFull) >> 32);
+}
 // a * b mod q for canonical a.  KPOOL: b comes from the constant pool (pre-scaled by 2^32 / 2^64 in
 // classes 2 / 3); otherwise b is a plain residue or small integer and those classes multiply exactly.
 template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(MV<CLS> a, u64 b, const ModCtx& mc) {
   if constexpr (CLS == 3 && KPOOL) return redc128_1((unsigned __int128)a * b, mc);
   else if constexpr (CLS == 2 && KPOOL) return redc64_1((u64)a * (u32)b, mc);
+  else if constexpr (CLS == 4 && KPOOL) return redc64_lazy((u64)a * (u32)b, mc);      // a < 2q, b < q: T / 2^32 < q / 16, result < 2q
   else if constexpr (wide<CLS>()) return mulmod(a, b, mc);
   else return barrett64((u64)a * (u32)b, mc);
 }
@@ -127,11 +139,15 @@ template <int CLS, bool KPOOL = true> __device__ __forceinline__ MV<CLS> m_mul(M
 // one output of a dense stage: sum_c v[c] * row[c] mod q
 template <int CLS, int D>
 __device__ __forceinline__ MV<CLS> m_dot(const MV<CLS> (&v)[D], const PT<CLS>* __restrict__ row, const ModCtx& mc) {
-  static_assert(D <= 16 || CLS == 2, "16 products below 2^124 fit in 128 bits");
-  if constexpr (CLS == 2) {      // D <= 13, or the merged prime powers (D = 18, 20) of plans whose moduli leave the room (plan.cpp)
+  static_assert(D <= 16 || c2<CLS>(), "16 products below 2^124 fit in 128 bits");
+  if constexpr (c2<CLS>()) {      // D <= 13, or the merged prime powers (D = 18, 20) of plans whose moduli leave the room (plan.cpp)
     u64 acc = 0;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc += (u64)v[c] * (u32)row[c];      // one v_mad_u64_u32 per term; D (q-1)^2 < 2^64
+    if constexpr (CLS == 4) {
+      const u32 r = redc64_lazy(acc, mc);             // D <= 16: < 2q;  D = 18, 20: T / 2^32 < 1.25 q, r < 2.25 q
+      if constexpr (D > 16) return min(r, r - 2 * (u32)mc.q); else return r;
+    } else
     return redc64(acc, mc);
   } else {
     unsigned __int128 acc = 0;
@@ -435,6 +451,7 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   constexpr int NE = 1 << K;
+  constexpr int AC = CLS == 4 ? 2 : CLS;       // class 4: the tiles compute on canonical residues with class 2's arithmetic
   const u64 q = mc.q;
   const int rts = FIRST ? 1 : st.rts, sh = FIRST ? 0 : st.p - 1;
   const int low = FIRST ? 0 : (tile & (rts - 1)), high = tile >> sh;
@@ -458,6 +475,12 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
 #pragma unroll
     for (int j = 0; j < NE; ++j) v[j] = base[j * rts];
   }
+  if constexpr (CLS == 4 && INV) {
+    if (st.pad[1]) {                     // the tile that follows the lazy dense stages of an inverse program: [0,2q) -> [0,q)
+#pragma unroll
+      for (int j = 0; j < NE; ++j) v[j] = min(v[j], v[j] - (u32)q);
+    }
+  }
   const PT<CLS>* tw = cst + st.tw_off + low;
   if constexpr (!INV) {
 #pragma unroll
@@ -466,10 +489,10 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         if (j & (1 << l)) continue;
-        const V t = m_mul<CLS>(v[j | (1 << l)], tw[half + (j & ((1 << l) - 1)) * rts], mc);
+        const V t = m_mul<AC>(v[j | (1 << l)], tw[half + (j & ((1 << l) - 1)) * rts], mc);
         const V x = v[j];
-        v[j] = m_add<CLS>(x, t, q);
-        v[j | (1 << l)] = m_sub<CLS>(x, t, q);
+        v[j] = m_add<AC>(x, t, q);
+        v[j | (1 << l)] = m_sub<AC>(x, t, q);
       }
     }
   } else {
@@ -480,14 +503,14 @@ __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict_
       for (int j = 0; j < NE; ++j) {
         if (j & (1 << l)) continue;
         const V x = v[j], y = v[j | (1 << l)];
-        v[j] = m_add<CLS>(x, y, q);
-        v[j | (1 << l)] = m_mul<CLS>(m_sub<CLS>(x, y, q), tw[half + (j & ((1 << l) - 1)) * rts], mc);
+        v[j] = m_add<AC>(x, y, q);
+        v[j | (1 << l)] = m_mul<AC>(m_sub<AC>(x, y, q), tw[half + (j & ((1 << l) - 1)) * rts], mc);
       }
     }
     if (st.mat_off >= 0) {             // this tile holds level 1: its X outputs take mhat^-1 here (the Y outputs through the table)
       const u64 mh = cst[st.mat_off];
 #pragma unroll
-      for (int j = 0; j < NE; j += 2) v[j] = m_mul<CLS>(v[j], mh, mc);
+      for (int j = 0; j < NE; j += 2) v[j] = m_mul<AC>(v[j], mh, mc);
     }
   }
   if (rts == 1) {
@@ -559,14 +582,14 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       if constexpr (HOIST) {
 #define LOLHIP_X(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV>(st, buf, it, cst, mc))) break;
 #define LOLHIP_X1(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc))) break;
-        if constexpr (CLS == 2) { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; } }
+        if constexpr (c2<CLS>()) { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; } }
         else { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; } }
 #undef LOLHIP_X1
 #undef LOLHIP_X
       } else {
 #define LOLHIP_X(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV>(st, buf, it, cst, mc); break;
 #define LOLHIP_X1(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc); break;
-        if constexpr (CLS == 2) { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; }) }
+        if constexpr (c2<CLS>()) { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; }) }
         else { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; }) }
 #undef LOLHIP_X1
 #undef LOLHIP_X
@@ -580,9 +603,9 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       const int wd = st.d <= 7 ? 4 : 2;            // vectors per thread
       // (two vectors per thread for d = 10..13 was tried: with the hoisted dispatch the 169-entry matrix and two
       // vectors spill 184 VGPRs to scratch in the fused poly-mul)
-      const bool wide = CLS == 2 && dense && st.d <= 7 && (st.rts & (wd - 1)) == 0 && (st.tw_off < 0 || (st.tw_div & (wd - 1)) == 0 || st.tw_mod == 1);
+      const bool wide = c2<CLS>() && dense && st.d <= 7 && (st.rts & (wd - 1)) == 0 && (st.tw_off < 0 || (st.tw_div & (wd - 1)) == 0 || st.tw_mod == 1);
       bool done = false;
-      if constexpr (CLS == 2) if (wide) {
+      if constexpr (c2<CLS>()) if (wide) {
         done = true;
         const int nqw = st.d <= 7 ? (nvec >> 2) : (nvec >> 1);      // rts | n / d, so nvec is a multiple of the width too
 #define LOLHIP_VECSW(X) X(2, 4) X(3, 4) X(4, 4) X(5, 4) X(6, 4) X(7, 4)
@@ -601,14 +624,14 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
         if constexpr (HOIST) {
 #define LOLHIP_X(D) case D: LOLHIP_LOOP(nvec, (stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
 #define LOLHIP_XL(D) case D: LOLHIP_LOOP(nvec, (stage_vec_big<CLS, D>(st, buf, it, cst, mc))) break;
-          if constexpr (CLS == 2 && BIG) { switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; } }
+          if constexpr (c2<CLS>() && BIG) { switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; } }
           else { switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; } }      // other lengths are excluded on the host (mixed_ok)
 #undef LOLHIP_XL
 #undef LOLHIP_X
         } else {
 #define LOLHIP_X(D) case D: stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
 #define LOLHIP_XL(D) case D: stage_vec_big<CLS, D>(st, buf, it, cst, mc); break;
-          if constexpr (CLS == 2 && BIG) { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; }) }
+          if constexpr (c2<CLS>() && BIG) { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; }) }
           else { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }) }
 #undef LOLHIP_XL
 #undef LOLHIP_X
@@ -639,7 +662,7 @@ template <int CLS> __device__ __forceinline__ MV<CLS> from_raw(i64 x, u64 q) {
 // poly-mul keeps a-hat and b's loads live and gets 128 (4 waves/SIMD), as does the 64-bit class
 // (at 80 it spills: measured slower).
 template <int CLS, int MODE, int KMAX, bool BIG = false>
-__global__ void __launch_bounds__(512, (MODE == 0 && CLS == 2) ? LOLHIP_MIXED_W2 : (MODE == 0 && CLS == 1) ? 6 : 4)
+__global__ void __launch_bounds__(512, (MODE == 0 && (CLS == 2 || CLS == 4)) ? LOLHIP_MIXED_W2 : (MODE == 0 && CLS == 1) ? 6 : 4)
 k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int ppw, i64 ngroups,
         const Stage* __restrict__ st_a, int n_a, const Stage* __restrict__ st_b, int n_b,
         const u64* __restrict__ consts64, const u32* __restrict__ consts32, int cpc, const ModCtx* __restrict__ mod) {
@@ -685,7 +708,14 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       const u32 o = goff();
       const int x0 = fresh(tid);
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) { const int x = x0 + k * nthr; if (k * nthr < tot) store_u64(wy, o, (u32)k * step, (u64)buf[x < tot ? x : 0]); }
+      for (int k = 0; k < KMAX; ++k) {
+        const int x = x0 + k * nthr;
+        if (k * nthr < tot) {
+          V r = buf[x < tot ? x : 0];
+          if constexpr (CLS == 4) r = min(r, r - (u32)mc.q);        // a program may end on a lazy stage: [0,2q) -> [0,q)
+          store_u64(wy, o, (u32)k * step, (u64)r);
+        }
+      }
     };
 
     u64 ra[KMAX];
@@ -757,7 +787,7 @@ hipError_t launch_cls_k(const MixedLaunch& a) {
 template <int CLS, int MODE>
 hipError_t launch_cls(const MixedLaunch& a) {
   const bool k12 = mixed_geom<CLS>(a).per_thread <= 12;
-  if constexpr (CLS == 2) if (a.big) return k12 ? launch_cls_k<CLS, MODE, 12, true>(a) : launch_cls_k<CLS, MODE, 16, true>(a);
+  if constexpr (c2<CLS>()) if (a.big) return k12 ? launch_cls_k<CLS, MODE, 12, true>(a) : launch_cls_k<CLS, MODE, 16, true>(a);
   return k12 ? launch_cls_k<CLS, MODE, 12>(a) : launch_cls_k<CLS, MODE, 16>(a);
 }
 

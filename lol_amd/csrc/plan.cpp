@@ -369,6 +369,8 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     for (auto& s : st) {
       const bool dense_odd = (s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV) && s.p > 2 && s.p <= 13 && s.d >= 3 && (s.d == s.p || s.d == s.p - 1);
       s.pad[0] = (cls3 && dense_odd) ? eo_off[s.p][inverse ? 1 : 0] : 0;
+      // class 4 (lazy dense stages): the inverse tile that follows a dense stage or a diagonal canonicalises what it loads
+      s.pad[1] = (s.kind == ST_POW2I && &s != &st.front() && (&s)[-1].kind != ST_POW2I) ? 1 : 0;
       s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod);
       const bool dense = s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV;
       s.tw_per = (!sw(SW_NO_OWN_DIAG) && dense && s.tw_off >= 0 && s.tw_mod > 1 && s.tw_div == s.rts && s.tw_mod % s.d == 0) ? s.tw_mod / s.d : 0;
@@ -689,8 +691,14 @@ int plan_upload(Plan& P) {
     if (q >= ((u64)1 << 61)) below61 = false;
   }
   P.mixed_cls = fits32 ? ((acc64 && odd) ? 2 : 1) : ((odd && below61) ? 3 : 0);
-  if (P.mixed_cls == 2 || P.mixed_cls == 3) {
-    const int sh = P.mixed_cls == 2 ? 32 : 64;
+  //   4: class 2 with every q below 2^27: lazy dense stages (values in [0,2q) between them: a 3-instruction Montgomery step)
+  if (P.mixed_cls == 2 && !sw(SW_NO_LAZY)) {
+    bool below27 = true;
+    for (u64 q : P.qs) if (q >= ((u64)1 << 27)) below27 = false;
+    if (below27) P.mixed_cls = 4;
+  }
+  if (P.mixed_cls == 2 || P.mixed_cls == 4 || P.mixed_cls == 3) {
+    const int sh = P.mixed_cls == 3 ? 64 : 32;
     std::vector<u64> mont(P.host_consts.size());
     for (int t = 0; t < T; ++t) {
       const u64 q = P.qs[(size_t)t];
@@ -701,7 +709,7 @@ int plan_upload(Plan& P) {
       }
     }
     if ((rc = upload(&P.d_consts_mont, mont))) return rc;
-    if (P.mixed_cls == 2) {
+    if (P.mixed_cls == 2 || P.mixed_cls == 4) {
       std::vector<uint32_t> c32(mont.begin(), mont.end());           // every entry is a residue below q < 2^32
       if ((rc = upload(&P.d_consts32, c32))) return rc;
     }

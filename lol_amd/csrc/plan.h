@@ -121,7 +121,7 @@ struct Plan {
   Pow2Tables pow2;
   bool is_pow2 = false;
   int device_id = -1;                       // HIP device the tables were uploaded to
-  int mixed_cls = 0;                        // arithmetic/storage class of the vector interpreter (mixed.hip)
+  int mixed_cls = 0;                        // arithmetic/storage class of the vector interpreter (mixed.hip): 0-3, 4 = 2 with lazy dense stages
   // floating-point side (floatpath.hip): the CRT stage lists over C — a second
   // constant pool, (re, im) interleaved, same offsets as host_consts — and the real maps of
   // tensorGaussianDec
@@ -155,7 +155,7 @@ void plan_free_device(Plan& P);
 // A/B switches of the launch paths (development and tests): read ONCE from the environment
 // (LOLHIP_<NAME>) into atomics; tests flip them through lolhip_debug_set, never through setenv
 // (getenv racing with setenv is undefined behaviour, and plans are used from concurrent threads).
-enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_NO_MERGE, SW_COUNT };
+enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_NO_MERGE, SW_NO_LAZY, SW_COUNT };
 bool sw(Switch which);
 inline bool pow2_no_t1() { return sw(SW_NO_T1); }
 

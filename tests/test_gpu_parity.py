@@ -320,6 +320,43 @@ def test_merged_prime_powers(gpu, cpuref, m):
             assert np.array_equal(P.crtInv(P.crt(y)), y)
 
 
+@pytest.mark.parametrize("m", [13, 25, 27, 225, 1575, 15015, 14400, 11648])
+def test_lazy_dense_stages_at_the_top_of_their_range(gpu, cpuref, m):
+    """Class 4 of the vector interpreter (every modulus below 2^27): dense stages hand values in [0,2q) to each other
+    and reduce with the bare 3-instruction Montgomery step, whose bound (T / 2^32 < q for 16 terms of values below 2q)
+    is tightest for the largest moduli and the largest residues.  Moduli just below 2^27, inputs of q - 1 everywhere,
+    alternating 0 / q - 1, negative representatives and random ones; against the oracle and against the same plan built
+    as class 2 (NO_LAZY); crt, crtInv, poly-mul, the G and L maps (which must still see canonical residues)."""
+    pps = lm.factor_pps(m)
+    g = lm.good_qs(m, 2 ** 27 - 2 ** 22)
+    qs = [q for q in (next(g) for _ in range(40)) if q < 2 ** 27][-2:]
+    assert qs and all(q < 2 ** 27 for q in qs)
+    for qsel in ([qs[-1]], qs):
+        R = Params(pps, qsel)
+        rng = np.random.default_rng(m)
+        B = 4 if R.n <= 2000 else 2
+        y = R.random(rng, B)
+        qv = np.array(qsel, dtype=np.int64)
+        y[0] = qv - 1                                    # every coefficient q - 1
+        y[1, ::2] = 0; y[1, 1::2] = qv - 1
+        if B > 2:
+            y[2] = -(qv - 1)                             # negative representatives (-q, 0]
+        z = R.random(rng, B); z[0] = qv - 1
+        want = {op: getattr(cpuref, op)(R, y) for op in ("crt", "crtinv") + PRIME_OPS}
+        wmul, wsq = cpuref.polymul(R, y, z), cpuref.polymul(R, y, y)
+        for lazy in (True, False):
+            gpu.debug_set("NO_LAZY", not lazy)
+            P = gpu.Plan(pps, qsel)
+            gpu.debug_set("NO_LAZY", False)
+            for op in ("crt", "crtinv") + PRIME_OPS:
+                got = getattr(P, PLAN_NAME[op])(y)
+                assert (got is None) == (want[op] is None), op
+                if got is not None:
+                    assert np.array_equal(got, want[op]), (op, m, qsel, lazy)
+            assert np.array_equal(P.polymul(y, z), wmul), (m, qsel, lazy)
+            assert np.array_equal(P.polymul(y, y), wsq), (m, qsel, lazy)
+
+
 @pytest.mark.parametrize("m", [12, 40, 48, 96, 160, 768, 1728, 2912, 11648, 14336, 2 ** 12 * 3])
 def test_two_power_factor_routes(gpu, cpuref, monkeypatch, m):
     """m = 2^e * odd: the innermost tensor factor CRT_{2^e} acts on contiguous blocks of 2^(e-1)
