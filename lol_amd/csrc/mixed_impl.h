@@ -442,19 +442,15 @@ __device__ __forceinline__ void stage_vecw(const Stage& st, MV<CLS>* __restrict_
 // odd primes' stages in any order.  (Unreduced butterflies for q < 2^27 — 7 instead of 12 instructions — were
 // built and measured twice: as a second path in this function they spill 66-99 VGPRs to scratch (crt of 64*9*25
 // 0.18 -> 0.31 ms); as separate instantiations they gain 0-5 % (2^11*7 crt 0.284 -> 0.269 ms) for +50 % build time.)
-// FIRST: the tile that starts at level 1 (rts = 1: contiguous, and the table index of every butterfly is a
-// compile-time constant, the same for every tile) — its twiddles are scalar loads into SGPR operands instead of
-// 2^K - 1 per-lane loads with their address arithmetic, which is what lets a 5-level tile (32 residues) fit the
-// 80-VGPR budget of the 32-bit single-program kernels.
-template <int CLS, int K, bool INV, bool FIRST = false>
+template <int CLS, int K, bool INV>
 __device__ __forceinline__ void stage_pow2(const Stage& st, MV<CLS>* __restrict__ buf, int tile,
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
   using V = MV<CLS>;
   constexpr int NE = 1 << K;
   constexpr int AC = CLS == 4 ? 2 : CLS;       // class 4: the tiles compute on canonical residues with class 2's arithmetic
   const u64 q = mc.q;
-  const int rts = FIRST ? 1 : st.rts, sh = FIRST ? 0 : st.p - 1;
-  const int low = FIRST ? 0 : (tile & (rts - 1)), high = tile >> sh;
+  const int rts = st.rts, sh = st.p - 1;
+  const int low = tile & (rts - 1), high = tile >> sh;
   V* base = buf + ((high << (sh + K)) | low);
   V v[NE];
   if (rts == 1) {                      // contiguous tile: 16-byte LDS accesses
@@ -547,17 +543,6 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
                                            const PT<CLS>* __restrict__ cst, const ModCtx& mc) {
 #define LOLHIP_LOOP(COUNT, CALL) for (int it = threadIdx.x; it < (COUNT); it += blockDim.x) { CALL; }
 #define LOLHIP_TILES(X) X(2, 1, false) X(3, 1, true) X(4, 2, false) X(5, 2, true) X(6, 3, false) X(7, 3, true) X(8, 4, false) X(9, 4, true)
-#ifndef LH_TILES_FIRST
-#define LH_TILES_FIRST 0      // A/B: the scalar-twiddle form of the tile that starts at level 1
-#endif
-#if !LH_TILES_FIRST
-#define LH_FIRST_SEL 0
-#define LOLHIP_TILES1(X)
-#else
-#define LH_FIRST_SEL 1
-#define LOLHIP_TILES1(X) X(18, 1, false) X(19, 1, true) X(20, 2, false) X(21, 2, true) X(22, 3, false) X(23, 3, true) X(24, 4, false) X(25, 4, true)
-#endif
-#define LOLHIP_TILES5(X)
 #define LOLHIP_VECS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(10) X(11) X(12) X(13)
 #ifdef LH_NO_VL
 #define LOLHIP_VECSL(X)
@@ -577,21 +562,14 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
       }
     } else if (st.kind == ST_POW2F || st.kind == ST_POW2I) {
       const int ntile = tot >> st.d;
-      // + 16: the tile that starts at level 1 (scalar twiddles; the only one that may hold 5 levels, class 2)
-      const int sel = st.d * 2 + (st.kind == ST_POW2I ? 1 : 0) + (LH_FIRST_SEL && st.rts == 1 ? 16 : 0);
+      const int sel = st.d * 2 + (st.kind == ST_POW2I ? 1 : 0);
       if constexpr (HOIST) {
 #define LOLHIP_X(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV>(st, buf, it, cst, mc))) break;
-#define LOLHIP_X1(SEL, K, INV) case SEL: LOLHIP_LOOP(ntile, (stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc))) break;
-        if constexpr (c2<CLS>()) { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; } }
-        else { switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; } }
-#undef LOLHIP_X1
+        switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; }
 #undef LOLHIP_X
       } else {
 #define LOLHIP_X(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV>(st, buf, it, cst, mc); break;
-#define LOLHIP_X1(SEL, K, INV) case SEL: stage_pow2<CLS, K, INV, true>(st, buf, it, cst, mc); break;
-        if constexpr (c2<CLS>()) { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) LOLHIP_TILES5(LOLHIP_X1) default: break; }) }
-        else { LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) LOLHIP_TILES1(LOLHIP_X1) default: break; }) }
-#undef LOLHIP_X1
+        LOLHIP_LOOP(ntile, switch (sel) { LOLHIP_TILES(LOLHIP_X) default: break; })
 #undef LOLHIP_X
       }
     } else {
@@ -642,8 +620,6 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
   }
 #undef LOLHIP_LOOP
 #undef LOLHIP_TILES
-#undef LOLHIP_TILES1
-#undef LOLHIP_TILES5
 #undef LOLHIP_VECS
 #undef LOLHIP_VECSL
 }

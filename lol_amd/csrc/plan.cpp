@@ -366,11 +366,12 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   int eo_off[16][2];
   for (auto& r : eo_off) r[0] = r[1] = 0;
   auto finish = [&](std::vector<Stage>& st, bool inverse = false) {
-    for (auto& s : st) {
+    for (size_t si = 0; si < st.size(); ++si) {
+      Stage& s = st[si];
       const bool dense_odd = (s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV) && s.p > 2 && s.p <= 13 && s.d >= 3 && (s.d == s.p || s.d == s.p - 1);
       s.pad[0] = (cls3 && dense_odd) ? eo_off[s.p][inverse ? 1 : 0] : 0;
       // class 4 (lazy dense stages): the inverse tile that follows a dense stage or a diagonal canonicalises what it loads
-      s.pad[1] = (s.kind == ST_POW2I && &s != &st.front() && (&s)[-1].kind != ST_POW2I) ? 1 : 0;
+      s.pad[1] = (s.kind == ST_POW2I && si > 0 && st[si - 1].kind != ST_POW2I) ? 1 : 0;
       s.m_rts = magic40(s.rts); s.m_d = magic40(s.d); s.m_twdiv = magic40(s.tw_div); s.m_twmod = magic40(s.tw_mod);
       const bool dense = s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV;
       s.tw_per = (!sw(SW_NO_OWN_DIAG) && dense && s.tw_off >= 0 && s.tw_mod > 1 && s.tw_div == s.rts && s.tw_mod % s.d == 0) ? s.tw_mod / s.d : 0;
