@@ -336,7 +336,7 @@ LOLHIP_API int64_t lolhip_chain_write(const uint8_t *const *elems, const int64_t
 LOLHIP_API int lolhip_copy_slab(void *stream, void *dst, const void *src, int64_t bytes, int variant);
 
 /* Test and A/B aid, not part of the drop-in surface: force a launch path.  `name` is one of
- * GENERIC_SCALAR, NO_FUSED2, NO_POW2_PART, POLYMUL_UNFUSED, KEYSWITCH_UNFUSED, NO_T1, NO_PIPE, FORCE_PIPE, NO_OWN_DIAG, NO_MERGE and NO_LAZY (these three read when a plan is built) (each is
+ * GENERIC_SCALAR, NO_FUSED2, NO_POW2_PART, POLYMUL_UNFUSED, KEYSWITCH_UNFUSED, NO_T1, NO_PIPE, FORCE_PIPE, NO_OWN_DIAG, NO_MERGE, NO_KRON and NO_LAZY (these four read when a plan is built) (each is
  * also read ONCE at first use from the environment variable LOLHIP_<name>); value 0 restores the
  * default path.  Every path computes the same residues.  Returns LOLHIP_OK or LOLHIP_ERR_INVALID. */
 LOLHIP_API int lolhip_debug_set(const char *name, int value);

@@ -25,7 +25,7 @@ using namespace lolhip;
 namespace lolhip {
 namespace {
 const char* const kSwitchNames[SW_COUNT] = {"GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED",
-                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE", "NO_LAZY"};
+                                            "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE", "NO_LAZY", "NO_KRON"};
 std::atomic<int> g_switch[SW_COUNT];
 std::once_flag g_switch_once;
 void switches_init() {

@@ -544,6 +544,7 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
 #define LOLHIP_LOOP(COUNT, CALL) for (int it = threadIdx.x; it < (COUNT); it += blockDim.x) { CALL; }
 #define LOLHIP_TILES(X) X(2, 1, false) X(3, 1, true) X(4, 2, false) X(5, 2, true) X(6, 3, false) X(7, 3, true) X(8, 4, false) X(9, 4, true)
 #define LOLHIP_VECS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(10) X(11) X(12) X(13)
+#define LOLHIP_VECS8(X) X(8)                                  // BIG kernels only: 3 (x) 5 as one stage (plan.cpp merge_stages<true>)
 #ifdef LH_NO_VL
 #define LOLHIP_VECSL(X)
 #else
@@ -602,14 +603,14 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
         if constexpr (HOIST) {
 #define LOLHIP_X(D) case D: LOLHIP_LOOP(nvec, (stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc))) break;
 #define LOLHIP_XL(D) case D: LOLHIP_LOOP(nvec, (stage_vec_big<CLS, D>(st, buf, it, cst, mc))) break;
-          if constexpr (c2<CLS>() && BIG) { switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; } }
+          if constexpr (c2<CLS>() && BIG) { switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECS8(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; } }
           else { switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; } }      // other lengths are excluded on the host (mixed_ok)
 #undef LOLHIP_XL
 #undef LOLHIP_X
         } else {
 #define LOLHIP_X(D) case D: stage_vec<CLS, D>(st, buf, it, n, n_magic, cst, mc); break;
 #define LOLHIP_XL(D) case D: stage_vec_big<CLS, D>(st, buf, it, cst, mc); break;
-          if constexpr (c2<CLS>() && BIG) { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; }) }
+          if constexpr (c2<CLS>() && BIG) { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) LOLHIP_VECS8(LOLHIP_X) LOLHIP_VECSL(LOLHIP_XL) default: break; }) }
           else { LOLHIP_LOOP(nvec, switch (st.d) { LOLHIP_VECS(LOLHIP_X) default: break; }) }
 #undef LOLHIP_XL
 #undef LOLHIP_X
@@ -621,6 +622,7 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
 #undef LOLHIP_LOOP
 #undef LOLHIP_TILES
 #undef LOLHIP_VECS
+#undef LOLHIP_VECS8
 #undef LOLHIP_VECSL
 }
 

@@ -204,20 +204,37 @@ static void build_crt_programs(const std::vector<PP>& pps, const Ring& R, PoolBu
 // (4 + 5) multiply-adds, two diagonal products and three reductions.  Built by pushing the unit vectors
 // through the staged form on the host; the merged stage replaces the run in a COPY of the program
 // (the floating-point path and the scalar interpreter keep the staged list).
-static bool merge_prime_powers(std::vector<Stage>& st, PoolBuilder& pool, const std::vector<u64>& qs, int max_phi) {
+// KRON: the second pass — two ADJACENT tensor factors that are one dense stage each (after the first pass: a prime or a
+// merged prime power) and whose Kronecker product is a vector length the kernels hold: 3 (x) 5 as ONE 8-vector stage
+// (m = 15015: five round trips become four), 3 (x) 7 as a 12-vector.  Same host construction, same residues.
+template <bool KRON>
+static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::vector<u64>& qs, int max_phi) {
   bool any = false;
   std::vector<Stage> out;
   for (size_t a = 0; a < st.size();) {
     auto dense = [](const Stage& s) { return s.kind == ST_DFTP || s.kind == ST_CRTP || s.kind == ST_CRTPINV; };
     size_t b = a;
-    if (dense(st[a]) && st[a].p > 2) { b = a + 1; while (b < st.size() && dense(st[b]) && st[b].p == st[a].p) ++b; }
+    if constexpr (!KRON) {
+      if (dense(st[a]) && st[a].p > 2) { b = a + 1; while (b < st.size() && dense(st[b]) && st[b].p == st[a].p) ++b; }
+    } else {
+      // st[a], st[a+1]: whole factors (no neighbour shares their prime), consecutive (stride of the second = stride * length
+      // of the first), no diagonal other than a single constant
+      auto whole = [&](size_t k) { return dense(st[k]) && st[k].p > 2 && (st[k].tw_off < 0 || st[k].tw_mod == 1) &&
+                                          (k == 0 || !dense(st[k - 1]) || st[k - 1].p != st[k].p) &&
+                                          (k + 1 >= st.size() || !dense(st[k + 1]) || st[k + 1].p != st[k].p); };
+      if (a + 1 < st.size() && whole(a) && whole(a + 1) && st[a].p != st[a + 1].p && (i64)st[a + 1].rts == (i64)st[a].rts * st[a].d) {
+        const int D = st[a].d * st[a + 1].d;
+        if (D == 8 || D == 12) b = a + 2;
+      }
+    }
     if (b < a + 2) { out.push_back(st[a]); ++a; continue; }
-    // the run [a, b) is one prime power: (I (x) A (x) I_R) with R the smallest stride in it
-    i64 R = st[a].rts; int e1 = 0; bool inv = false;
-    for (size_t k = a; k < b; ++k) { R = std::min<i64>(R, st[k].rts); if (st[k].kind == ST_DFTP) ++e1; else if (st[k].kind == ST_CRTPINV) inv = true; }
+    // the run [a, b) is (I (x) A (x) I_R) with R the smallest stride in it and A of the largest extent d * stride / R
+    i64 R = st[a].rts; bool inv = false;
+    for (size_t k = a; k < b; ++k) { R = std::min<i64>(R, st[k].rts); if (st[k].kind == ST_CRTPINV) inv = true; }
     const int p = st[a].p;
-    const i64 phi = (i64)(p - 1) * ipow(p, e1);
-    bool ok = phi <= max_phi && (size_t)(e1 + 1) == b - a;
+    i64 phi = 1;
+    for (size_t k = a; k < b; ++k) phi = std::max<i64>(phi, (i64)st[k].d * (st[k].rts / R));
+    bool ok = phi <= max_phi;
     for (size_t k = a; k < b && ok; ++k) {
       const Stage& s = st[k];
       if (s.rts % R || phi % ((i64)s.d * (s.rts / R))) ok = false;
@@ -226,7 +243,7 @@ static bool merge_prime_powers(std::vector<Stage>& st, PoolBuilder& pool, const 
         else { const i64 kdiv = s.tw_div / R; if (phi % kdiv || (phi / kdiv) % s.tw_mod) ok = false; }
       }
     }
-    if (!ok) { for (size_t k = a; k < b; ++k) out.push_back(st[k]); a = b; continue; }
+    if (!ok) { if (KRON) { out.push_back(st[a]); ++a; } else { for (size_t k = a; k < b; ++k) out.push_back(st[k]); a = b; } continue; }
     const int mat = pool.per_comp([&](int t, std::vector<u64>& o) {
       const u64 q = qs[(size_t)t];
       const std::vector<u64>& tab = pool.pool[(size_t)t];
@@ -496,26 +513,32 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
     finish(fused_f, false); finish(fused_i, true);
     P.fused2 = true;
   }
-  // class 2: small prime powers as one dense stage each (merge_prime_powers; plan.h says which program runs where)
+  // class 2: small prime powers as one dense stage each (merge_stages; plan.h says which program runs where)
   for (StageProgram* sp : {&P.prog_crt_mg, &P.prog_crtinv_mg, &P.prog_crt_mg_big, &P.prog_crtinv_mg_big, &P.prog_crt_fused_big, &P.prog_crtinv_fused_big})
     sp->stages.clear();
   if (cls2 && P.has_crt && !sw(SW_NO_MERGE)) {
-    auto has_big = [](const std::vector<Stage>& st) { for (const Stage& s : st) if (s.kind != ST_POW2F && s.kind != ST_POW2I && s.d > 13) return true; return false; };
+    // "big": a dense vector length only the BIG kernels hold — 18, 20 (merged 3^3, 5^2) and 8 (3 (x) 5)
+    auto has_big = [](const std::vector<Stage>& st) { for (const Stage& s : st) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8)) return true; return false; };
     // both directions of a pair get the same treatment (the fused poly-mul launches them together)
-    auto merged_pair = [&](const std::vector<Stage>& f0, const std::vector<Stage>& i0, int phi, std::vector<Stage>& f, std::vector<Stage>& i) {
+    auto merged_pair = [&](const std::vector<Stage>& f0, const std::vector<Stage>& i0, int phi, bool kron, std::vector<Stage>& f, std::vector<Stage>& i) {
       f = f0; i = i0;
-      const bool mf = merge_prime_powers(f, pool, qs, phi), mi = merge_prime_powers(i, pool, qs, phi);
+      bool mf = merge_stages<false>(f, pool, qs, phi), mi = merge_stages<false>(i, pool, qs, phi);
       if (mf != mi) { f = f0; i = i0; return false; }
+      if (kron && !sw(SW_NO_KRON)) {
+        std::vector<Stage> f1 = f, i1 = i;
+        const bool kf = merge_stages<true>(f1, pool, qs, 13), ki = merge_stages<true>(i1, pool, qs, 13);
+        if (kf && ki) { f = f1; i = i1; mf = true; }
+      }
       if (mf) { finish(f, false); finish(i, true); }
       return mf;
     };
     std::vector<Stage> f, i;
     if (!fused_f.empty()) {
-      if (max_phi > 13 && merged_pair(fused_f, fused_i, max_phi, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_fused_big.stages = f; P.prog_crtinv_fused_big.stages = i; }
-      if (merged_pair(fused_f, fused_i, 13, f, i)) { fused_f = f; fused_i = i; }
+      if (merged_pair(fused_f, fused_i, max_phi, true, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_fused_big.stages = f; P.prog_crtinv_fused_big.stages = i; }
+      if (merged_pair(fused_f, fused_i, 13, false, f, i)) { fused_f = f; fused_i = i; }
     }
-    if (max_phi > 13 && merged_pair(crt.st, crtinv.st, max_phi, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_mg_big.stages = f; P.prog_crtinv_mg_big.stages = i; }
-    if (merged_pair(crt.st, crtinv.st, 13, f, i)) { P.prog_crt_mg.stages = f; P.prog_crtinv_mg.stages = i; }
+    if (merged_pair(crt.st, crtinv.st, max_phi, true, f, i) && (has_big(f) || has_big(i))) { P.prog_crt_mg_big.stages = f; P.prog_crtinv_mg_big.stages = i; }
+    if (merged_pair(crt.st, crtinv.st, 13, false, f, i)) { P.prog_crt_mg.stages = f; P.prog_crtinv_mg.stages = i; }
   }
   P.prog_crt_fused.stages = fused_f;
   P.prog_crtinv_fused.stages = fused_i;
@@ -592,7 +615,7 @@ static int upload(Tp** dptr, const std::vector<Tp>& h) {
 static int upload_prog(StageProgram& sp) {
   sp.nstages = (int)sp.stages.size();
   sp.big = false;
-  for (const Stage& s : sp.stages) if (s.kind != ST_POW2F && s.kind != ST_POW2I && s.d > 13) sp.big = true;
+  for (const Stage& s : sp.stages) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8)) sp.big = true;
   return upload(&sp.d_stages, sp.stages);
 }
 

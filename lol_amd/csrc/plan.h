@@ -60,7 +60,7 @@ struct StageProgram {
   std::vector<Stage> stages;   // host copy
   Stage* d_stages = nullptr;   // device copy
   int nstages = 0;
-  bool big = false;            // holds a dense vector longer than 13 (merged 3^3 / 5^2): the BIG kernels of class 2 only
+  bool big = false;            // holds a dense vector of length 18, 20 (merged 3^3 / 5^2) or 8 (3 (x) 5): the BIG kernels of classes 2 / 4 only
 };
 
 // ---- power-of-two fast path -------------------------------------------------
@@ -155,7 +155,7 @@ void plan_free_device(Plan& P);
 // A/B switches of the launch paths (development and tests): read ONCE from the environment
 // (LOLHIP_<NAME>) into atomics; tests flip them through lolhip_debug_set, never through setenv
 // (getenv racing with setenv is undefined behaviour, and plans are used from concurrent threads).
-enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_NO_MERGE, SW_NO_LAZY, SW_COUNT };
+enum Switch { SW_GENERIC_SCALAR, SW_NO_FUSED2, SW_NO_POW2_PART, SW_POLYMUL_UNFUSED, SW_KEYSWITCH_UNFUSED, SW_NO_T1, SW_NO_PIPE, SW_FORCE_PIPE, SW_NO_OWN_DIAG, SW_NO_MERGE, SW_NO_LAZY, SW_NO_KRON, SW_COUNT };
 bool sw(Switch which);
 inline bool pow2_no_t1() { return sw(SW_NO_T1); }
 

@@ -56,7 +56,7 @@ def gpu(lolhip):
     return lolhip
 
 
-SWITCHES = ("GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED", "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE", "NO_LAZY")
+SWITCHES = ("GENERIC_SCALAR", "NO_FUSED2", "NO_POW2_PART", "POLYMUL_UNFUSED", "KEYSWITCH_UNFUSED", "NO_T1", "NO_PIPE", "FORCE_PIPE", "NO_OWN_DIAG", "NO_MERGE", "NO_LAZY", "NO_KRON")
 
 
 @pytest.fixture(autouse=True)

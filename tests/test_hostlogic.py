@@ -162,3 +162,8 @@ def test_class2_plans_merge_small_prime_powers():
         assert prog(q26) == prog(q45)
     finally:
         lol_amd.debug_set("NO_MERGE", False)
+    # adjacent small factors as one Kronecker stage: 3 (x) 5 = an 8-vector (BASELINE config 4's index); not for 64-bit residues
+    q30, q60 = lm.first_good_q(15015, 2 ** 30), lm.first_good_q(15015, 2 ** 60)
+    assert prog(q30, m=15015) == [(2, 3, 8, 1), (2, 7, 6, 8), (2, 11, 10, 48), (2, 13, 12, 480)]
+    assert prog(q30, True, m=15015) == [(3, 3, 8, 1), (3, 7, 6, 8), (3, 11, 10, 48), (3, 13, 12, 480)]
+    assert [r[2] for r in prog(q60, m=15015)] == [2, 4, 6, 10, 12]
