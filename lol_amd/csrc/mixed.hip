@@ -34,7 +34,7 @@ bool mixed_ok(i64 n, const Stage* host_stages, int nstages, const u64* qs, int T
     if (st.kind == ST_DIAG || st.kind == ST_SCALE) continue;
     if (st.kind == ST_POW2F || st.kind == ST_POW2I) { if (st.d < 1 || st.d > 4) return false; continue; }
     const int d = st.d;
-    if (!(d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 8 || d == 10 || d == 11 || d == 12 || d == 13 || d == 18 || d == 20)) return false;      // 18, 20: merged prime powers, class 2 / 4 plans only (plan.cpp)
+    if (!(d == 2 || d == 3 || d == 4 || d == 5 || d == 6 || d == 7 || d == 8 || d == 9 || d == 10 || d == 11 || d == 12 || d == 13 || d == 18 || d == 20)) return false;      // 18, 20: merged prime powers, class 2 / 4 plans only (plan.cpp)
   }
   return true;
 }

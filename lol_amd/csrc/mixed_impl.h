@@ -544,7 +544,7 @@ __device__ __forceinline__ void run_stages(MV<CLS>* __restrict__ buf, int tot, i
 #define LOLHIP_LOOP(COUNT, CALL) for (int it = threadIdx.x; it < (COUNT); it += blockDim.x) { CALL; }
 #define LOLHIP_TILES(X) X(2, 1, false) X(3, 1, true) X(4, 2, false) X(5, 2, true) X(6, 3, false) X(7, 3, true) X(8, 4, false) X(9, 4, true)
 #define LOLHIP_VECS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(10) X(11) X(12) X(13)
-#define LOLHIP_VECS8(X) X(8)                                  // BIG kernels only: 3 (x) 5 as one stage (plan.cpp merge_stages<true>)
+#define LOLHIP_VECS8(X) X(8) X(9)                                // BIG kernels only: 3 (x) 5 as one stage (plan.cpp merge_stages<true>)
 #ifdef LH_NO_VL
 #define LOLHIP_VECSL(X)
 #else

@@ -208,7 +208,7 @@ static void build_crt_programs(const std::vector<PP>& pps, const Ring& R, PoolBu
 // merged prime power) and whose Kronecker product is a vector length the kernels hold: 3 (x) 5 as ONE 8-vector stage
 // (m = 15015: five round trips become four), 3 (x) 7 as a 12-vector.  Same host construction, same residues.
 template <bool KRON>
-static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::vector<u64>& qs, int max_phi) {
+static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::vector<u64>& qs, int max_phi, bool big) {      // big: lengths of the BIG kernels (8, 9) allowed
   bool any = false;
   std::vector<Stage> out;
   for (size_t a = 0; a < st.size();) {
@@ -229,21 +229,43 @@ static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::v
     }
     if (b < a + 2) { out.push_back(st[a]); ++a; continue; }
     // the run [a, b) is (I (x) A (x) I_R) with R the smallest stride in it and A of the largest extent d * stride / R
-    i64 R = st[a].rts; bool inv = false;
-    for (size_t k = a; k < b; ++k) { R = std::min<i64>(R, st[k].rts); if (st[k].kind == ST_CRTPINV) inv = true; }
+    auto extent = [&](size_t lo, size_t hi, i64& R, i64& phi) {
+      R = st[lo].rts;
+      for (size_t k = lo; k < hi; ++k) R = std::min<i64>(R, st[k].rts);
+      phi = 1;
+      for (size_t k = lo; k < hi; ++k) phi = std::max<i64>(phi, (i64)st[k].d * (st[k].rts / R));
+    };
+    const size_t a0 = a, b0 = b;              // the whole run; [a, b) becomes the part that is merged
+    i64 R, phi;
+    extent(a, b, R, phi);
+    if constexpr (!KRON) {
+      // a power of 3 too long for one vector (3^4 = 81: 54): its two OUTERMOST radix-3 stages and the diagonal between
+      // them are DFT_9 on 9-vectors of their own — one stage instead of two (64 * 81 is a reference benchmark index)
+      if (big && phi > max_phi && st[a].p == 3 && b - a >= 3 && max_phi >= 9) {
+        if (st[b - 1].kind == ST_DFTP && st[b - 2].kind == ST_DFTP && st[b - 1].rts > st[b - 2].rts) a = b - 2;           // forward: the last two
+        else if (st[a].kind == ST_DFTP && st[a + 1].kind == ST_DFTP && st[a].rts > st[a + 1].rts) b = a + 2;             // inverse: the first two
+        extent(a, b, R, phi);
+      }
+    }
+    bool inv = false;
+    for (size_t k = a; k < b; ++k) if (st[k].kind == ST_CRTPINV) inv = true;
     const int p = st[a].p;
-    i64 phi = 1;
-    for (size_t k = a; k < b; ++k) phi = std::max<i64>(phi, (i64)st[k].d * (st[k].rts / R));
     bool ok = phi <= max_phi;
+    bool carry = false;                       // the last stage's diagonal reaches beyond the merged block: it stays the merged stage's diagonal
     for (size_t k = a; k < b && ok; ++k) {
       const Stage& s = st[k];
       if (s.rts % R || phi % ((i64)s.d * (s.rts / R))) ok = false;
       if (s.tw_off >= 0 && s.tw_mod > 1) {
-        if (s.tw_div % R) ok = false;
-        else { const i64 kdiv = s.tw_div / R; if (phi % kdiv || (phi / kdiv) % s.tw_mod) ok = false; }
+        bool inside = s.tw_div % R == 0;
+        if (inside) { const i64 kdiv = s.tw_div / R; inside = phi % kdiv == 0 && (phi / kdiv) % s.tw_mod == 0; }
+        if (!inside) { if (k + 1 == b) carry = true; else ok = false; }
       }
     }
-    if (!ok) { if (KRON) { out.push_back(st[a]); ++a; } else { for (size_t k = a; k < b; ++k) out.push_back(st[k]); a = b; } continue; }
+    if (!ok) {
+      if (KRON) { out.push_back(st[a0]); a = a0 + 1; } else { for (size_t k = a0; k < b0; ++k) out.push_back(st[k]); a = b0; }
+      continue;
+    }
+    for (size_t k = a0; k < a; ++k) out.push_back(st[k]);
     const int mat = pool.per_comp([&](int t, std::vector<u64>& o) {
       const u64 q = qs[(size_t)t];
       const std::vector<u64>& tab = pool.pool[(size_t)t];
@@ -261,7 +283,7 @@ static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::v
               for (i64 i = 0; i < d; ++i) {
                 u64 acc = 0;
                 for (i64 j = 0; j < d; ++j) acc = (acc + mulmod(tab[(size_t)(s.mat_off + i * d + j)] % q, v[(size_t)j], q)) % q;
-                if (s.tw_off >= 0) {
+                if (s.tw_off >= 0 && !(carry && k + 1 == b)) {
                   const i64 xl = x0 + i * stride;
                   const i64 idx = s.tw_mod > 1 ? (xl / (s.tw_div / R)) % s.tw_mod : 0;
                   acc = mulmod(acc, tab[(size_t)(s.tw_off + idx)] % q, q);
@@ -278,9 +300,11 @@ static bool merge_stages(std::vector<Stage>& st, PoolBuilder& pool, const std::v
     std::memset(&m, 0, sizeof(m));
     m.kind = inv ? ST_CRTPINV : ST_CRTP; m.p = p; m.d = (int32_t)phi; m.rts = (int32_t)R; m.wp_off = st[a].wp_off;
     m.tw_off = -1; m.tw_mod = 1; m.tw_div = 1; m.mat_off = mat;
+    if (carry) { m.tw_off = st[b - 1].tw_off; m.tw_mod = st[b - 1].tw_mod; m.tw_div = st[b - 1].tw_div; }
     out.push_back(m);
+    for (size_t k = b; k < b0; ++k) out.push_back(st[k]);
     any = true;
-    a = b;
+    a = b0;
   }
   if (any) st.swap(out);
   return any;
@@ -517,16 +541,16 @@ int plan_build_host(Plan& P, const std::vector<PP>& pps, const std::vector<u64>&
   for (StageProgram* sp : {&P.prog_crt_mg, &P.prog_crtinv_mg, &P.prog_crt_mg_big, &P.prog_crtinv_mg_big, &P.prog_crt_fused_big, &P.prog_crtinv_fused_big})
     sp->stages.clear();
   if (cls2 && P.has_crt && !sw(SW_NO_MERGE)) {
-    // "big": a dense vector length only the BIG kernels hold — 18, 20 (merged 3^3, 5^2) and 8 (3 (x) 5)
-    auto has_big = [](const std::vector<Stage>& st) { for (const Stage& s : st) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8)) return true; return false; };
+    // "big": a dense vector length only the BIG kernels hold — 18, 20 (merged 3^3, 5^2), 8 (3 (x) 5), 9 (DFT_9 of 3^e, e >= 4)
+    auto has_big = [](const std::vector<Stage>& st) { for (const Stage& s : st) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8 || s.d == 9)) return true; return false; };
     // both directions of a pair get the same treatment (the fused poly-mul launches them together)
     auto merged_pair = [&](const std::vector<Stage>& f0, const std::vector<Stage>& i0, int phi, bool kron, std::vector<Stage>& f, std::vector<Stage>& i) {
       f = f0; i = i0;
-      bool mf = merge_stages<false>(f, pool, qs, phi), mi = merge_stages<false>(i, pool, qs, phi);
+      bool mf = merge_stages<false>(f, pool, qs, phi, kron), mi = merge_stages<false>(i, pool, qs, phi, kron);
       if (mf != mi) { f = f0; i = i0; return false; }
       if (kron && !sw(SW_NO_KRON)) {
         std::vector<Stage> f1 = f, i1 = i;
-        const bool kf = merge_stages<true>(f1, pool, qs, 13), ki = merge_stages<true>(i1, pool, qs, 13);
+        const bool kf = merge_stages<true>(f1, pool, qs, 13, true), ki = merge_stages<true>(i1, pool, qs, 13, true);
         if (kf && ki) { f = f1; i = i1; mf = true; }
       }
       if (mf) { finish(f, false); finish(i, true); }
@@ -615,7 +639,7 @@ static int upload(Tp** dptr, const std::vector<Tp>& h) {
 static int upload_prog(StageProgram& sp) {
   sp.nstages = (int)sp.stages.size();
   sp.big = false;
-  for (const Stage& s : sp.stages) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8)) sp.big = true;
+  for (const Stage& s : sp.stages) if (s.kind != ST_POW2F && s.kind != ST_POW2I && (s.d > 13 || s.d == 8 || s.d == 9)) sp.big = true;
   return upload(&sp.d_stages, sp.stages);
 }
 

@@ -294,7 +294,7 @@ def test_generic_indices(gpu, cpuref, m):
         assert np.array_equal(P.divGCRT(P.mulGCRT(y)), y)
 
 
-@pytest.mark.parametrize("m", [9, 25, 27, 45, 225, 675, 1575, 1728, 3200, 14400, 192, 384, 3072, 6144, 11648, 15, 105, 1155, 15015, 21, 273])
+@pytest.mark.parametrize("m", [9, 25, 27, 45, 225, 675, 1575, 1728, 3200, 14400, 192, 384, 3072, 6144, 11648, 15, 105, 1155, 15015, 21, 273, 81, 243, 5184, 405])
 def test_merged_prime_powers(gpu, cpuref, m):
     """Class 2 of the vector interpreter (32-bit residues, one 64-bit accumulator per dot product): the plan
     replaces CRT_{p^e} for 3^2, 5^2, 3^3 by ONE dense phi x phi stage and the adjacent factors 3 (x) 5, 3 (x) 7 by one Kronecker

@@ -167,3 +167,7 @@ def test_class2_plans_merge_small_prime_powers():
     assert prog(q30, m=15015) == [(2, 3, 8, 1), (2, 7, 6, 8), (2, 11, 10, 48), (2, 13, 12, 480)]
     assert prog(q30, True, m=15015) == [(3, 3, 8, 1), (3, 7, 6, 8), (3, 11, 10, 48), (3, 13, 12, 480)]
     assert [r[2] for r in prog(q60, m=15015)] == [2, 4, 6, 10, 12]
+    # 3^4 is too long for one vector: its two outermost radix-3 stages run as one DFT_9 stage (64 * 81, Benchmarks/Default.hs:42-46)
+    q81 = lm.first_good_q(5184, 2 ** 26)
+    assert prog(q81, m=5184) == [(12, 1, 4, 1), (12, 5, 1, 16), (2, 3, 2, 32), (1, 3, 3, 64), (2, 3, 9, 192)]
+    assert prog(q81, True, m=5184) == [(2, 3, 9, 192), (1, 3, 3, 64), (3, 3, 2, 32), (13, 5, 1, 16), (13, 1, 4, 1)]
