@@ -708,7 +708,8 @@ k_mixed(i64* y_out, const i64* a_in, const i64* b_in, i64 B, int T, int n, int p
       to_lds(ra);
       // b's loads go out now and land under a's stages (holding them back to fit a third
       // workgroup per CU measured 0.125 vs 0.122 ms on config 4: not worth it)
-      // (BIG: b's 2 KMAX raw registers would spill under the 20-element vectors: loaded after a's stages instead)
+      // (BIG: b's 2 KMAX raw registers would spill under the 20-element vectors: loaded after a's stages instead; in the
+      // 12-coefficient variant, where they fit, the early load measured 2-3 % SLOWER at m = 15015, q ~ 2^29)
       if constexpr (!BIG) if (!square) load16(ra, __builtin_amdgcn_make_buffer_rsrc((void*)(b_in + gbase), 0, wbytes, 0x00020000));
       __syncthreads();
       run_stages<CLS, HOISTED, BIG>(buf, tot, n, n_magic, st_a, n_a, cst, mc);
