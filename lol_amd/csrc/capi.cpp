@@ -182,7 +182,8 @@ int do_crt(const Plan& P, hipStream_t s, int64_t* y, int64_t B, bool inverse) {
   if (P.is_pow2) return run_pow2(P, inverse ? 1 : 0, s, y, nullptr, nullptr, B);
   // a lone transform of m = 2^e * odd: one launch of the interpreter, except with 64-bit residues and
   // e >= 5, where the m = 2^k kernels' cheaper butterflies outweigh the second pass over the slab
-  // (measured at 58 bits: m = 11648 0.62 vs 0.55 ms, m = 14336 0.65 vs 0.52 ms; at 26 bits fused wins everywhere)
+  // (measured at 58 bits: m = 11648 0.62 vs 0.55 ms, m = 14336 0.65 vs 0.52 ms; with the even/odd form of round 3 0.54 vs 0.48 and
+  // 0.62 vs 0.50, m = 14400 0.457 vs 0.448; at 26 bits fused wins everywhere)
   const bool wide = P.mixed_cls == 0 || P.mixed_cls == 3;
   if (use_fused2(P) && !(wide && P.pow2_part)) return run_prog(P, inverse ? fused_crtinv(P) : fused_crt(P), s, y, B);
   if (P.pow2_part && !sw(SW_NO_POW2_PART)) {
