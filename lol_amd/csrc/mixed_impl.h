@@ -353,7 +353,7 @@ __device__ __forceinline__ void stage_vec(const Stage& st, MV<CLS>* __restrict__
   for (int i = 0; i < D; ++i) base[i * rts] = o[i];
 }
 
-// a merged prime power (plan.cpp merge_prime_powers: D = 18, 20; no diagonal): every output is stored as soon as
+// a merged prime power (plan.cpp merge_stages: D = 18, 20; no diagonal): every output is stored as soon as
 // its dot product is reduced — the D inputs are in registers by then — so D + 3 values are live, not 2 D
 template <int CLS, int D>
 __device__ __forceinline__ void stage_vec_big(const Stage& st, MV<CLS>* __restrict__ buf, int vec,

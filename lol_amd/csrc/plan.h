@@ -110,11 +110,12 @@ struct Plan {
   // reference's own parameter sets (64*27, 64*81, 64*9*25, 128*7*13 ...) a fused 3-pass kernel.
   bool fused2 = false;
   StageProgram prog_crt_fused, prog_crtinv_fused;
-  // class 2 of the vector interpreter: prime powers of small totient as ONE dense stage each (plan.cpp
-  // merge_prime_powers).  Totients up to 13 (3^2) run in every kernel: prog_crt_fused / prog_crtinv_fused are merged
+  // classes 2 / 4 of the vector interpreter: prime powers of small totient as ONE dense stage each (plan.cpp
+  // merge_stages).  Totients up to 13 (3^2) run in every kernel: prog_crt_fused / prog_crtinv_fused are merged
   // in place, prog_crt_mg / prog_crtinv_mg are the merged copies of prog_crt / prog_crtinv (empty when nothing
-  // merges).  Totients 18 and 20 (3^3, 5^2) need the BIG kernels (mixed_impl.h): the *_big programs, empty when they
-  // would equal the others; lone transforms and the fused poly-mul take them, the fused key switch does not.
+  // merges).  Vector lengths 18 and 20 (3^3, 5^2), 8 (3 (x) 5 as one Kronecker stage) and 9 (the DFT_9 tail of 3^e,
+  // e >= 4) need the BIG kernels (mixed_impl.h): the *_big programs, empty when they would equal the others; lone
+  // transforms and the fused poly-mul take them, the fused key switch at <= 12 coefficients per thread.
   StageProgram prog_crt_mg, prog_crtinv_mg, prog_crt_mg_big, prog_crtinv_mg_big, prog_crt_fused_big, prog_crtinv_fused_big;
   i64* d_gcrt = nullptr;                    // [n*T]
   i64* d_ginvcrt = nullptr;                 // [n*T]

@@ -144,7 +144,7 @@ def test_device_code_has_no_unpadded_wide_store(lolhip):
 
 
 def test_class2_plans_merge_small_prime_powers():
-    """plan.cpp merge_prime_powers / tile grouping, on host-only plans (no GPU): what a lone crt of the
+    """plan.cpp merge_stages / tile grouping, on host-only plans (no GPU): what a lone crt of the
     reference's benchmark index 64*9*25 (Benchmarks/Default.hs:49-50) launches.  Kinds: 12/13 = 2-power tile
     forward/inverse, 1 = DFT_p, 2 = CRT_p, 3 = CRT_p^-1 (plan.h)."""
     import lol_amd

@@ -1,5 +1,5 @@
 #!/bin/bash
-# merged prime-power stages (plan.cpp merge_prime_powers), class 2 of the vector interpreter: same box, three builds
+# merged prime-power stages (plan.cpp merge_stages), class 2 of the vector interpreter: same box, three builds
 #   new    : this library (18-/20-vectors instantiated)            merged programs / staged programs (LOLHIP_NO_MERGE)
 
 #   old    : without the 18-/20-vector instantiations (-DLH_NO_VL: the round's earlier kernel), staged programs only
